@@ -1,0 +1,146 @@
+"""Plat-style model facade: the drop-in for the reference's API.py.
+
+``IAN(config_path, dnn)`` keeps API.py's surface (API.py:11-110) so that NPE.py's call sequence
+(NPE.py:18,110,205,218,257,261,296,311,323,333,335) runs unchanged:
+
+    model = IAN(config_path='IAN_simple.py', dnn=True)
+    z  = model.encode_images(x)            # f32[n,3,64,64] in [-1,1] -> f32[n,100]
+    x_ = model.sample_at(z)                # f32[n,100] -> f32[n,3,64,64]
+    g  = model.imgradRGB(c1,r1,c2,r2,RGB,z); g2 = model.imgrad(c1,r1,c2,r2,z)
+    model.get_zdim(); model.cfg; model.model
+
+Everything numerical happens in libian.so (hand-written HIP, include/ian.h); this class only reads
+the config, loads the checkpoint and moves numpy buffers across the C ABI.  Extra methods give the
+four function equivalents sample_IAN.py compiles for itself (sample_IAN.py:86-94).
+"""
+from __future__ import annotations
+
+import logging
+import os
+import warnings
+
+import numpy as np
+
+from . import checkpoints, config_loader, lowering, made
+from .lib import Handle
+
+
+class IAN:
+    def __init__(self, config_path, dnn=True, params=None, deconv_flip=True):
+        """config_path, dnn: as API.py:12.  ``params`` (optional extension): dict of Theano-named arrays
+        used instead of the '<config>.npz' checkpoint (tests and the benchmark use synthetic weights
+        because the reference's weight files are absent)."""
+        config_module = config_loader.load_config(config_path)
+        self.cfg = config_module.cfg                                   # API.py:19
+        self.weights_fname = str(config_path)[:-3] + ".npz"            # API.py:20
+        self.model = config_loader.build_model(config_module, dnn=dnn)  # API.py:21
+        self.lowered = lowering.lower_model(self.model)
+        self._h = Handle(self.lowered, deconv_flip=deconv_flip)
+        self.metadata = {}
+
+        # Load weights (API.py:23-30)
+        specs = self.lowered.params
+        if params is None:
+            params = {}
+            if os.path.exists(self.weights_fname):
+                try:
+                    params, self.metadata = checkpoints.load_weights(self.weights_fname, lowering.all_param_specs(self.model))
+                except Exception as exc:  # e.g. a git-LFS pointer instead of the archive
+                    warnings.warn("could not read %s (%s); parameters keep their initial values" % (self.weights_fname, exc))
+            else:
+                warnings.warn("weights file %s not found; parameters keep their initial values" % self.weights_fname)
+        rs = np.random.RandomState(0)
+        for p in specs:
+            arr = params.get(p.name)
+            if arr is None:
+                logging.warning("unable to load parameter %s", p.name)
+                arr = p.init.sample(p.shape, rs)
+            elif tuple(np.shape(arr)) != p.shape:
+                raise ValueError("parameter %s has shape %s, expected %s" % (p.name, np.shape(arr), p.shape))
+            self._h.load_param(p.name, arr)
+
+        # Shuffle weights if using IAF with MADE (API.py:32-36): reset("Once") on both MADEs
+        if "l_IAF_mu" in self.model:
+            self.model["l_IAF_mu"].reset("Once")
+            self.model["l_IAF_ls"].reset("Once")
+        if self.lowered.has_made:
+            self.made_masks = made.masks_once(self.lowered.num_latents)
+            self._h.set_made_masks(*self.made_masks)
+        self._h.finalize()
+        self._zdim = self.lowered.num_latents
+
+    # ---- helpers -------------------------------------------------------------------------------------
+    @staticmethod
+    def _f32(a, shape_tail, what):
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        if a.ndim != len(shape_tail) + 1 or tuple(a.shape[1:]) != tuple(shape_tail):
+            raise ValueError("%s must have shape (n,%s), got %s" % (what, ",".join(map(str, shape_tail)), a.shape))
+        if a.shape[0] < 1:
+            raise ValueError("%s is empty" % what)
+        return a
+
+    def _run(self, fn, src, out_tail):
+        out = np.empty((src.shape[0],) + tuple(out_tail), np.float32)
+        self._h.call(fn, src, src.shape[0], out)
+        return out
+
+    # ---- API.py surface ------------------------------------------------------------------------------
+    def imgrad(self, c1, r1, c2, r2, z):
+        """API.py:66-70: change in latents which would lighten the local image patch."""
+        z = self._f32(z, (self._zdim,), "z")
+        dz = np.empty((1, self._zdim), np.float32)
+        self._h.grad_light(int(c1), int(r1), int(c2), int(r2), z[:1], dz)
+        return dz
+
+    def imgradRGB(self, c1, r1, c2, r2, RGB, z):
+        """API.py:72-76: change in latents which would move the patch towards RGB."""
+        z = self._f32(z, (self._zdim,), "z")
+        rgb = self._f32(RGB, (3, 64, 64), "RGB")
+        dz = np.empty((1, self._zdim), np.float32)
+        self._h.grad_rgb(int(c1), int(r1), int(c2), int(r2), rgb[:1], z[:1], dz)
+        return dz
+
+    def encode_images(self, images):
+        """API.py:78-90: n x 3 x 64 x 64 in [-1,1] -> n x zdim."""
+        return self._run("ian_encode", self._f32(images, (3, 64, 64), "images"), (self._zdim,))
+
+    def get_zdim(self):
+        """API.py:92-96."""
+        return self.cfg["num_latents"]
+
+    def sample_at(self, z):
+        """API.py:98-110: n x zdim -> n x 3 x 64 x 64."""
+        return self._run("ian_decode", self._f32(z, (self._zdim,), "z"), (3, 64, 64))
+
+    # ---- sample_IAN.py function equivalents ----------------------------------------------
+    def sampleZ(self, z):
+        """sample_IAN.py:88: l_Z -> l_out (same as sample_at)."""
+        return self.sample_at(z)
+
+    def Zfn(self, images):
+        """sample_IAN.py:90-91: image -> l_Z_IAF (deterministic)."""
+        return self._run("ian_encode_pre_iaf", self._f32(images, (3, 64, 64), "images"), (self._zdim,))
+
+    def Z_IAF_fn(self, z):
+        """sample_IAN.py:93-94: l_Z_IAF -> l_Z."""
+        return self._run("ian_iaf", self._f32(z, (self._zdim,), "z"), (self._zdim,))
+
+    def sample(self, z):
+        """sample_IAN.py:86: l_Z_IAF -> l_out."""
+        return self.sample_at(self.Z_IAF_fn(z))
+
+    def reconstruct(self, images):
+        """encode_images followed by sample_at with the latent kept on the device (bench config 2)."""
+        return self._run("ian_reconstruct", self._f32(images, (3, 64, 64), "images"), (3, 64, 64))
+
+    # ---- introspection ---------------------------------------------------------------------------------
+    def activation(self, name, n):
+        """Activation (NCHW) of the named layer output from the last call (tests / debugging)."""
+        return self._h.read_slot(self.lowered.slot_by_name(name), n)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        self._h.close()

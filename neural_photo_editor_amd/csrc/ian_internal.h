@@ -1,0 +1,125 @@
+// Internal declarations shared by the runtime (ian_runtime.cpp) and the device code (kernels_*.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ian {
+
+// ---------------------------------------------------------------------------------------------
+// "tap GEMM": every dense-channel layer of the IAN (5x5/s2 conv, 5x5/s2 transposed conv split into
+// its 4 output-parity classes, composite multiscale-dilated 3x3, dense) is one implicit GEMM
+//     C[m][co] = sum_t sum_ci  X[pixel(m) + d_t][ci] * Wt[t][co][ci]
+// over a list of taps t = (dy,dx, weight slab).  m enumerates (image, qy, qx) of a per-class output
+// grid; input pixel = q*si + b + d_t, output pixel = q*so + p_class.
+// ---------------------------------------------------------------------------------------------
+struct TgTap {
+  int dy, dx;
+};
+struct TgClass {
+  int ntaps, tap0;  // taps[tap0 .. tap0+ntaps)
+  int py, px;       // output parity offset
+  long long w_off;  // float offset of this class's first weight slab; slab t at w_off + t*CoutPad*Cin
+};
+struct TgItem {  // one workgroup's job (host-built table, 32 B)
+  int cls, m0, n0;
+  int ks0, ks1;  // K-step range [ks0,ks1) of 32-channel steps over (tap, ci-chunk)
+  int slab;      // split-K: slab tile index; -1 = direct epilogue
+  int pad0, pad1;
+};
+struct TgTile {  // reduce pass: one output tile
+  int cls, m0, n0, slab0, nsplit, pad0, pad1, pad2;
+};
+
+enum { TG_EPI_FWD = 0, TG_EPI_BWD = 1 };
+
+struct TgEpilogue {
+  const float* scale;  // per output channel (folded BN gamma*inv_std) or nullptr (=1)
+  const float* shift;  // per output channel (folded beta/bias) or nullptr (=0)
+  const float* res;    // residual tensor, same layout as y, added before the affine; or nullptr
+  const float* yfwd;   // BWD: forward output of the layer whose pre-activation gradient is produced
+  int act;             // enum ian_act
+  int mode;            // TG_EPI_FWD: y = act((acc+res)*scale+shift)
+                       // TG_EPI_BWD: y = (acc [+res]) * act'(yfwd) * scale   (gradient wrt pre-affine value)
+};
+
+struct TgParams {
+  const float* x;
+  const float* w;
+  float* y;
+  float* slab;
+  const TgItem* items;
+  const TgClass* classes;
+  const TgTap* taps;
+  TgEpilogue epi;
+  int M;                     // images * QH * QW
+  int IH, IW, Cin;           // Cin = padded input channels = pixel stride of x (multiple of 32)
+  int qw_shift, qhw_shift;   // QW = 1<<qw_shift, QH*QW = 1<<qhw_shift
+  int si, by, bx;            // input coordinate = q*si + b + d
+  int so;                    // output coordinate = q*so + p
+  int OH, OW, Cout, y_stride;
+  int CoutPad;
+};
+
+struct TgReduceParams {
+  const float* slab;
+  float* y;
+  const TgTile* tiles;
+  const TgClass* classes;
+  TgEpilogue epi;
+  int M, qw_shift, qhw_shift, so, OH, OW, Cout, y_stride;
+};
+
+enum TgConfig { TG_128x128 = 0, TG_128x64 = 1, TG_64x64 = 2, TG_32x128 = 3, TG_256x128 = 4, TG_128x32 = 5, TG_NCONFIG = 6 };
+struct TgShape {
+  int bm, bn;
+};
+static inline TgShape tg_shape(int cfg) {
+  switch (cfg) {
+    case TG_128x128: return {128, 128};
+    case TG_128x64: return {128, 64};
+    case TG_64x64: return {64, 64};
+    case TG_32x128: return {32, 128};
+    case TG_128x32: return {128, 32};
+    default: return {256, 128};
+  }
+}
+
+hipError_t launch_tapgemm(int cfg, const TgParams& p, int nitems, hipStream_t s);
+hipError_t launch_tapgemm_reduce(int cfg, const TgReduceParams& p, int ntiles, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// edge layers (3 image channels) and small ops
+// ---------------------------------------------------------------------------------------------
+// enc_conv1: x NCHW [n,3,H,W] -> y NHWC [n,H/2,W/2,Cout], 5x5 s2 p2 + bias + act. w packed [75][Cout].
+hipError_t launch_conv1_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y, int n,
+                             int H, int W, int Cout, int act, hipStream_t s);
+// dec_out: x NHWC [n,H,W,Cin] -> y NCHW [n,Cout(<=4),2H,2W], 5x5 s2 transposed conv + affine + act.
+// w packed [25 (ky,kx)][Cout4=4][Cin].
+hipError_t launch_deconv_out_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                                  int n, int H, int W, int Cin, int Cout, int act, hipStream_t s);
+
+// y = act(x*scale[c]+shift[c]) on NHWC tensors (pixel stride = stride)
+hipError_t launch_affine(const float* x, float* y, const float* scale, const float* shift, long long npix, int C,
+                         int stride, int act, hipStream_t s);
+// MADE x2 + IAF on latent rows (stride zs): z' = (z - made_mu(z)) / exp(made_ls(z)); weights pre-masked [6][100][100]+[6][100]
+hipError_t launch_made_iaf(const float* z, float* zo, const float* wts, const float* bias, int n, int d, int zs,
+                           hipStream_t s);
+// beta_layer x3 + concat -> NCHW output [n,3,H,W]; R,G,B are NHWC with 2 channels (stride rs)
+hipError_t launch_beta(const float* R, const float* G, const float* B, float* y, int n, int hw, int rs, hipStream_t s);
+// channel concat of two NHWC tensors
+hipError_t launch_concat2(const float* a, int ca, int sa, const float* b, int cb, int sb, float* y, int sy,
+                          long long npix, hipStream_t s);
+// layout / copy helpers
+hipError_t launch_rows_copy(const float* src, int src_stride, float* dst, int dst_stride, int n, int c, hipStream_t s);
+hipError_t launch_nhwc_to_nchw(const float* src, int stride, float* dst, int n, int hw, int c, hipStream_t s);
+// loss seeds for the latent-brush gradients (API.py:59,64): writes d loss / d x_hat (NCHW [1,3,H,W], zero outside patch)
+hipError_t launch_patch_seed(const float* xhat, const float* rgb, float* g, int H, int W, int c1, int r1, int c2,
+                             int r2, int mode, hipStream_t s);
+// backward of dec_out-like layer: g NCHW [n,Cout,2H,2W] (already multiplied by act') -> dx NHWC [n,H,W,Cin]
+hipError_t launch_deconv_out_bwd(const float* g, const float* w, float* dx, const float* yfwd, const float* scale,
+                                 int n, int H, int W, int Cin, int Cout, int act, hipStream_t s);
+// elementwise: g = g * act'(y) * scale  (NCHW small tensors, c channels of hw pixels)
+hipError_t launch_dact_nchw(float* g, const float* y, const float* scale, int n, int c, int hw, int act,
+                            hipStream_t s);
+
+}  // namespace ian

@@ -1,0 +1,1194 @@
+// libian.so runtime: model handle, parameter folding / repacking, work-table scheduling, executor, C ABI.
+// Host-side C++ (compiled by hipcc for the HIP host API); all arithmetic on activations is in the
+// kernels_*.hip files.  See include/ian.h for the contract and the reference lines each entry replaces.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ian.h"
+#include "ian_internal.h"
+
+using namespace ian;
+
+namespace {
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    return n;
+  }
+};
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline int ilog2_exact(int v) {
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return ((1 << s) == v) ? s : -1;
+}
+
+struct Schedule {
+  int cfg = 0;
+  int nitems = 0;
+  TgItem* d_items = nullptr;
+  int ntiles = 0;  // >0 => split-K: slabs + reduce pass
+  TgTile* d_tiles = nullptr;
+  size_t slab_tiles = 0;
+  std::vector<TgItem> h_items;  // kept for tests / debugging
+  std::vector<TgTile> h_tiles;
+};
+
+// one linear map executed by the tapgemm kernel (forward or backward-data form of an op)
+struct TgLayer {
+  bool valid = false;
+  int IH = 1, IW = 1, Cin = 32, QH = 1, QW = 1, si = 1, by = 0, bx = 0, so = 1, OH = 1, OW = 1, Cout = 0, CoutPad = 0;
+  int cin_real = 0;  // for FLOP accounting
+  std::vector<TgClass> classes;
+  std::vector<TgTap> taps;
+  std::vector<float> h_w;  // packed weights (freed after upload unless keep_host)
+  float* d_w = nullptr;
+  TgClass* d_classes = nullptr;
+  TgTap* d_taps = nullptr;
+  std::map<int, Schedule> sched;  // per batch size
+  double macs_per_image() const {
+    double m = 0;
+    for (auto& c : classes) m += (double)QH * QW * c.ntaps * cin_real * Cout;
+    return m;
+  }
+};
+
+struct Slot {
+  int h = 1, w = 1, c = 1, cs = 32;
+  bool nchw = false;  // external-layout tensors (image in / image out)
+  float* d = nullptr;
+  float* g = nullptr;  // gradient wrt the producer's pre-epilogue value (latent-brush backward)
+  size_t cap = 0, gcap = 0;
+  size_t per_image() const { return nchw ? (size_t)c * h * w : (size_t)h * w * cs; }
+};
+
+struct OpPlan {
+  ian_op_desc d;
+  std::string name, bn_name;
+  TgLayer fwd, bwd;
+  bool edge = false;  // 3-channel edge kernel instead of tapgemm
+  float* d_edge_w = nullptr;
+  std::vector<float> h_edge_w;
+  float* d_scale = nullptr;
+  float* d_shift = nullptr;
+  std::vector<float> h_scale, h_shift;
+  float* d_made_w = nullptr;
+  float* d_made_b = nullptr;
+};
+
+struct Options {
+  int tg_cfg = -1;            // force a tile config (enum TgConfig) or -1 = auto
+  int tg_target_items = 768;  // split-K aims at about this many workgroups
+  int tg_min_steps = 16;      // never make a K-range shorter than this many 32-channel steps
+  int tg_no_split_items = 384;  // do not split when tiles alone give at least this many workgroups
+  int tg_split = 1;
+  int tg_xcd_group = 8;       // supergroup edge (tiles) dealt to one XCD
+};
+
+}  // namespace
+
+struct ian_handle {
+  ian_model_desc desc;
+  std::vector<OpPlan> ops;
+  std::vector<Slot> slots;
+  std::vector<std::string> strings;
+  std::map<std::string, HostTensor> params;
+  std::vector<float> made_masks[3];
+  int made_n = 0;
+  bool finalized = false;
+  Options opt;
+  std::string err;
+  // workspaces
+  float* d_slab = nullptr;
+  size_t slab_cap = 0;
+  float* d_stage_in = nullptr;
+  size_t stage_in_cap = 0;
+  float* d_stage_out = nullptr;
+  size_t stage_out_cap = 0;
+  float* d_gseed = nullptr;  // 3*H*W gradient seed
+  float* d_rgb = nullptr;
+  // profiling
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_total;
+  size_t ev_total_used = 0;
+  double prof_flops = 0;
+  int64_t prof_launches = 0;
+};
+
+namespace {
+
+int fail(ian_handle* h, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                            \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return fail(h, -2, "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+  } while (0)
+
+const HostTensor* find_param(ian_handle* h, const std::string& n) {
+  auto it = h->params.find(n);
+  return it == h->params.end() ? nullptr : &it->second;
+}
+
+int need_param(ian_handle* h, const std::string& n, std::initializer_list<int64_t> shape, const HostTensor** out) {
+  const HostTensor* t = find_param(h, n);
+  if (!t) return fail(h, -3, "missing parameter '%s'", n.c_str());
+  std::vector<int64_t> want(shape);
+  if (t->shape != want) {
+    std::string a, b;
+    for (auto s : t->shape) a += std::to_string(s) + ",";
+    for (auto s : want) b += std::to_string(s) + ",";
+    return fail(h, -3, "parameter '%s' has shape (%s) expected (%s)", n.c_str(), a.c_str(), b.c_str());
+  }
+  *out = t;
+  return 0;
+}
+
+template <typename T>
+int upload(ian_handle* h, const std::vector<T>& v, T** dptr) {
+  if (v.empty()) {
+    *dptr = nullptr;
+    return 0;
+  }
+  HIPCHK(h, hipMalloc((void**)dptr, v.size() * sizeof(T)));
+  HIPCHK(h, hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// ----- epilogue vectors: fold BatchNorm (App. B.3) and bias into y = acc*scale + shift --------------
+int build_affine(ian_handle* h, OpPlan& op, int features, const std::vector<int>* perm) {
+  std::vector<float> sc(features, 1.f), sh(features, 0.f);
+  const HostTensor* b = nullptr;
+  if (op.d.has_bias) {
+    int rc = need_param(h, op.name + ".b", {features}, &b);
+    if (rc) return rc;
+  }
+  if (!op.bn_name.empty()) {
+    const HostTensor *g, *be, *m, *is;
+    int rc;
+    if ((rc = need_param(h, op.bn_name + ".gamma", {features}, &g))) return rc;
+    if ((rc = need_param(h, op.bn_name + ".beta", {features}, &be))) return rc;
+    if ((rc = need_param(h, op.bn_name + ".mean", {features}, &m))) return rc;
+    if ((rc = need_param(h, op.bn_name + ".inv_std", {features}, &is))) return rc;
+    for (int i = 0; i < features; ++i) {
+      const float s = g->data[i] * is->data[i];
+      sc[i] = s;
+      // (x + b - mean)*s + beta
+      sh[i] = be->data[i] + ((b ? b->data[i] : 0.f) - m->data[i]) * s;
+    }
+  } else if (b) {
+    for (int i = 0; i < features; ++i) sh[i] = b->data[i];
+  }
+  const int padded = round_up(features, 128);
+  op.h_scale.assign(padded, 1.f);
+  op.h_shift.assign(padded, 0.f);
+  for (int i = 0; i < features; ++i) {
+    const int dst = perm ? (*perm)[i] : i;
+    op.h_scale[dst] = sc[i];
+    op.h_shift[dst] = sh[i];
+  }
+  return 0;
+}
+
+// reference (C,H,W)-flattened index -> internal (H,W,C) index
+std::vector<int> chw_to_hwc_perm(int C, int H, int W) {
+  std::vector<int> p((size_t)C * H * W);
+  for (int c = 0; c < C; ++c)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) p[((size_t)c * H + y) * W + x] = (y * W + x) * C + c;
+  return p;
+}
+
+void add_class(TgLayer& L, int py, int px, const std::vector<TgTap>& taps, long long w_off) {
+  TgClass c;
+  c.ntaps = (int)taps.size();
+  c.tap0 = (int)L.taps.size();
+  c.py = py;
+  c.px = px;
+  c.w_off = w_off;
+  L.classes.push_back(c);
+  for (auto& t : taps) L.taps.push_back(t);
+}
+
+// ----- weight repacking ------------------------------------------------------------------------------
+// CONV5S2 forward: IAN_simple.py:73-116. W (Cout,Cin,5,5); slab t=ky*5+kx: [CoutPad][CinPad] = W[co,ci,ky,kx]
+int pack_conv_fwd(ian_handle* h, OpPlan& op) {
+  const int cin = op.d.cin, cout = op.d.cout, H = op.d.in_h, W = op.d.in_w;
+  const HostTensor* Wt;
+  int rc = need_param(h, op.name + ".W", {cout, cin, 5, 5}, &Wt);
+  if (rc) return rc;
+  if (cin < 8) {  // edge kernel: [75][Cout], k=(c*5+ky)*5+kx
+    op.edge = true;
+    op.h_edge_w.assign((size_t)75 * cout, 0.f);
+    for (int co = 0; co < cout; ++co)
+      for (int c = 0; c < cin; ++c)
+        for (int k = 0; k < 25; ++k) op.h_edge_w[(size_t)(c * 25 + k) * cout + co] = Wt->data[((size_t)co * cin + c) * 25 + k];
+    return 0;
+  }
+  TgLayer& L = op.fwd;
+  L.valid = true;
+  L.IH = H; L.IW = W; L.Cin = round_up(cin, 32); L.cin_real = cin;
+  L.QH = H / 2; L.QW = W / 2; L.si = 2; L.by = -2; L.bx = -2; L.so = 1; L.OH = H / 2; L.OW = W / 2;
+  L.Cout = cout; L.CoutPad = round_up(cout, 128);
+  std::vector<TgTap> taps;
+  for (int ky = 0; ky < 5; ++ky)
+    for (int kx = 0; kx < 5; ++kx) taps.push_back({ky, kx});
+  add_class(L, 0, 0, taps, 0);
+  const size_t slab = (size_t)L.CoutPad * L.Cin;
+  L.h_w.assign(slab * 25, 0.f);
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int k = 0; k < 25; ++k) L.h_w[k * slab + (size_t)co * L.Cin + ci] = Wt->data[((size_t)co * cin + ci) * 25 + k];
+  return 0;
+}
+
+// DECONV5S2: layers.py:436-483. W (Cin,Cout,5,5). out[oy] += x[iy]*W[ci,co,kt], oy=2iy-2+ky, kt=flip?4-k:k.
+// forward: 4 parity classes; backward-data: 25-tap stride-2 "conv" over dY with [ci][co] slabs.
+int pack_deconv(ian_handle* h, OpPlan& op) {
+  const int cin = op.d.cin, cout = op.d.cout, H = op.d.in_h, W = op.d.in_w;
+  const bool flip = h->desc.deconv_flip != 0;
+  const HostTensor* Wt;
+  int rc = need_param(h, op.name + ".W", {cin, cout, 5, 5}, &Wt);
+  if (rc) return rc;
+  auto wref = [&](int ci, int co, int ky, int kx) {
+    const int ty = flip ? 4 - ky : ky, tx = flip ? 4 - kx : kx;
+    return Wt->data[(((size_t)ci * cout + co) * 5 + ty) * 5 + tx];
+  };
+  if (cout <= 4) {  // edge kernel: [25][4][Cin]
+    op.edge = true;
+    op.h_edge_w.assign((size_t)25 * 4 * cin, 0.f);
+    for (int ky = 0; ky < 5; ++ky)
+      for (int kx = 0; kx < 5; ++kx)
+        for (int co = 0; co < cout; ++co)
+          for (int ci = 0; ci < cin; ++ci) op.h_edge_w[((size_t)(ky * 5 + kx) * 4 + co) * cin + ci] = wref(ci, co, ky, kx);
+    return 0;
+  }
+  {
+    TgLayer& L = op.fwd;
+    L.valid = true;
+    L.IH = H; L.IW = W; L.Cin = round_up(cin, 32); L.cin_real = cin;
+    L.QH = H; L.QW = W; L.si = 1; L.by = 0; L.bx = 0; L.so = 2; L.OH = 2 * H; L.OW = 2 * W;
+    L.Cout = cout; L.CoutPad = round_up(cout, 128);
+    const size_t slab = (size_t)L.CoutPad * L.Cin;
+    L.h_w.assign(slab * 25, 0.f);
+    size_t t_global = 0;
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        std::vector<TgTap> taps;
+        const long long w_off = (long long)(t_global * slab);
+        for (int ky = py; ky < 5; ky += 2)
+          for (int kx = px; kx < 5; kx += 2) {
+            taps.push_back({(py + 2 - ky) / 2, (px + 2 - kx) / 2});
+            float* dst = L.h_w.data() + t_global * slab;
+            for (int co = 0; co < cout; ++co)
+              for (int ci = 0; ci < cin; ++ci) dst[(size_t)co * L.Cin + ci] = wref(ci, co, ky, kx);
+            ++t_global;
+          }
+        add_class(L, py, px, taps, w_off);
+      }
+  }
+  {
+    TgLayer& L = op.bwd;  // dX[iy,ix,ci] = sum dY[2iy-2+ky, 2ix-2+kx, co] * Wt[ci,co,ky,kx]
+    L.valid = true;
+    L.IH = 2 * H; L.IW = 2 * W; L.Cin = round_up(cout, 32); L.cin_real = cout;
+    L.QH = H; L.QW = W; L.si = 2; L.by = -2; L.bx = -2; L.so = 1; L.OH = H; L.OW = W;
+    L.Cout = cin; L.CoutPad = round_up(cin, 128);
+    std::vector<TgTap> taps;
+    for (int ky = 0; ky < 5; ++ky)
+      for (int kx = 0; kx < 5; ++kx) taps.push_back({ky, kx});
+    add_class(L, 0, 0, taps, 0);
+    const size_t slab = (size_t)L.CoutPad * L.Cin;
+    L.h_w.assign(slab * 25, 0.f);
+    for (int ky = 0; ky < 5; ++ky)
+      for (int kx = 0; kx < 5; ++kx) {
+        float* dst = L.h_w.data() + (size_t)(ky * 5 + kx) * slab;
+        for (int ci = 0; ci < cin; ++ci)
+          for (int co = 0; co < cout; ++co) dst[(size_t)ci * L.Cin + co] = wref(ci, co, ky, kx);
+      }
+  }
+  return 0;
+}
+
+// MDC3: layers.py:207-258 collapsed into ONE composite sparse stencil (the idea sketched -- and broken --
+// in layers.py:138-150 mdclW): offsets d*(p-1,q-1) for d in {1} + {s>0}, centre tap shared by all
+// branches and by the 1x1 mean branch.  slab[offset][co][ci] = sum_b coeff_b[co] * W[co,ci,p,q].
+int pack_mdc(ian_handle* h, OpPlan& op) {
+  const int cin = op.d.cin, cout = op.d.cout, H = op.d.in_h, W = op.d.in_w;
+  const HostTensor *Wt, *cb;
+  int rc;
+  if ((rc = need_param(h, op.name + "W", {cout, cin, 3, 3}, &Wt))) return rc;
+  if ((rc = need_param(h, op.name + "_coeff_base", {cout}, &cb))) return rc;
+  struct Branch {
+    int d;
+    const HostTensor* coeff;
+  };
+  std::vector<Branch> br;
+  br.push_back({1, cb});
+  const HostTensor* c1x1 = nullptr;
+  for (int i = 0; i < op.d.n_scales; ++i) {
+    const int s = op.d.scales[i];
+    const HostTensor* c;
+    if (s == 0) {
+      if ((rc = need_param(h, op.name + "_coeff_1x1", {cout}, &c))) return rc;
+      c1x1 = c;
+    } else {
+      if ((rc = need_param(h, op.name + "_coeff_" + std::to_string(s), {cout}, &c))) return rc;
+      br.push_back({s, c});
+    }
+  }
+  std::map<std::pair<int, int>, int> index;  // offset -> tap id
+  std::vector<TgTap> taps;
+  auto tap_id = [&](int dy, int dx) {
+    auto key = std::make_pair(dy, dx);
+    auto it = index.find(key);
+    if (it != index.end()) return it->second;
+    const int id = (int)taps.size();
+    index[key] = id;
+    taps.push_back({dy, dx});
+    return id;
+  };
+  tap_id(0, 0);
+  for (auto& b : br)
+    for (int p = 0; p < 3; ++p)
+      for (int q = 0; q < 3; ++q) tap_id(b.d * (p - 1), b.d * (q - 1));
+  const int nt = (int)taps.size();
+  auto fill = [&](TgLayer& L, bool transpose) {
+    L.valid = true;
+    L.IH = H; L.IW = W; L.QH = H; L.QW = W; L.si = 1; L.by = 0; L.bx = 0; L.so = 1; L.OH = H; L.OW = W;
+    const int kin = transpose ? cout : cin, kout = transpose ? cin : cout;
+    L.Cin = round_up(kin, 32); L.cin_real = kin; L.Cout = kout; L.CoutPad = round_up(kout, 128);
+    const size_t slab = (size_t)L.CoutPad * L.Cin;
+    L.h_w.assign(slab * nt, 0.f);
+    auto acc = [&](int t, int co, int ci, float v) {
+      if (!transpose) L.h_w[t * slab + (size_t)co * L.Cin + ci] += v;
+      else L.h_w[t * slab + (size_t)ci * L.Cin + co] += v;
+    };
+    for (auto& b : br)
+      for (int p = 0; p < 3; ++p)
+        for (int q = 0; q < 3; ++q) {
+          const int t = index[std::make_pair(b.d * (p - 1), b.d * (q - 1))];
+          for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+              acc(t, co, ci, b.coeff->data[co] * Wt->data[(((size_t)co * cin + ci) * 3 + p) * 3 + q]);
+        }
+    if (c1x1) {
+      for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+          float m = 0.f;
+          for (int k = 0; k < 9; ++k) m += Wt->data[((size_t)co * cin + ci) * 9 + k];
+          acc(0, co, ci, c1x1->data[co] * (m / 9.f));
+        }
+    }
+    std::vector<TgTap> tt = taps;
+    if (transpose)
+      for (auto& t : tt) { t.dy = -t.dy; t.dx = -t.dx; }
+    add_class(L, 0, 0, tt, 0);
+  };
+  fill(op.fwd, false);
+  fill(op.bwd, true);
+  return 0;
+}
+
+// DENSE: x.W (+b); W (in,out).  forward slab [CoutPad][CinPad] = W^T with the (C,H,W)->(H,W,C) permutations
+// of App. B.6 baked in; backward-data slab [in][out].
+int pack_dense(ian_handle* h, OpPlan& op, std::vector<int>& out_perm, bool& has_out_perm) {
+  const int fin = op.d.cin, fout = op.d.cout;
+  const HostTensor* Wt;
+  int rc = need_param(h, op.name + ".W", {fin, fout}, &Wt);
+  if (rc) return rc;
+  std::vector<int> in_perm;
+  const bool has_in = op.d.flat_c > 0;
+  if (has_in) in_perm = chw_to_hwc_perm(op.d.flat_c, op.d.flat_h, op.d.flat_w);
+  has_out_perm = op.d.unflat_c > 0;
+  if (has_out_perm) out_perm = chw_to_hwc_perm(op.d.unflat_c, op.d.unflat_h, op.d.unflat_w);
+  auto setup = [&](TgLayer& L, int kin, int kout) {
+    L.valid = true;
+    L.Cin = round_up(kin, 32); L.cin_real = kin; L.Cout = kout; L.CoutPad = round_up(kout, 128);
+    add_class(L, 0, 0, {{0, 0}}, 0);
+    L.h_w.assign((size_t)L.CoutPad * L.Cin, 0.f);
+  };
+  setup(op.fwd, fin, fout);
+  setup(op.bwd, fout, fin);
+  for (int i = 0; i < fin; ++i) {
+    const int ii = has_in ? in_perm[i] : i;
+    for (int j = 0; j < fout; ++j) {
+      const int jj = has_out_perm ? out_perm[j] : j;
+      const float v = Wt->data[(size_t)i * fout + j];
+      op.fwd.h_w[(size_t)jj * op.fwd.Cin + ii] = v;
+      op.bwd.h_w[(size_t)ii * op.bwd.Cin + jj] = v;
+    }
+  }
+  return 0;
+}
+
+int pack_made(ian_handle* h, OpPlan& op) {
+  const int d = op.d.cin;
+  if (h->made_n != d) return fail(h, -3, "MADE masks not set (ian_set_made_masks) or wrong size");
+  static const char* which[2] = {"_mu", "_ls"};
+  static const char* lay[3] = {"_input", "_output_W", "_output_D"};
+  const int mask_of[3] = {0, 1, 2};
+  std::vector<float> w((size_t)6 * d * d), b((size_t)6 * d);
+  for (int m = 0; m < 2; ++m)
+    for (int l = 0; l < 3; ++l) {
+      const std::string base = op.name + which[m] + lay[l];
+      const HostTensor *Wt, *bt;
+      int rc;
+      if ((rc = need_param(h, base + ".W", {d, d}, &Wt))) return rc;
+      if ((rc = need_param(h, base + ".b", {d}, &bt))) return rc;
+      const std::vector<float>& mask = h->made_masks[mask_of[l]];
+      float* wd = w.data() + (size_t)(m * 3 + l) * d * d;
+      for (int i = 0; i < d * d; ++i) wd[i] = Wt->data[i] * mask[i];  // layers.py:671,703: W * weights_mask
+      for (int i = 0; i < d; ++i) b[(size_t)(m * 3 + l) * d + i] = bt->data[i];
+    }
+  int rc;
+  if ((rc = upload(h, w, &op.d_made_w))) return rc;
+  return upload(h, b, &op.d_made_b);
+}
+
+int upload_layer(ian_handle* h, TgLayer& L) {
+  if (!L.valid) return 0;
+  if (ilog2_exact(L.QW) < 0 || ilog2_exact(L.QH * L.QW) < 0) return fail(h, -4, "tapgemm needs power-of-two output grids");
+  int rc;
+  if ((rc = upload(h, L.h_w, &L.d_w))) return rc;
+  if ((rc = upload(h, L.classes, &L.d_classes))) return rc;
+  if ((rc = upload(h, L.taps, &L.d_taps))) return rc;
+  std::vector<float>().swap(L.h_w);
+  return 0;
+}
+
+// ----- scheduling: tiles, split-K, heavy-first + XCD-aware item order ---------------------------------
+int pick_config(const ian_handle* h, const TgLayer& L, int M) {
+  if (h->opt.tg_cfg >= 0 && h->opt.tg_cfg < TG_NCONFIG) {
+    const TgShape s = tg_shape(h->opt.tg_cfg);
+    if (L.CoutPad % s.bn == 0) return h->opt.tg_cfg;
+  }
+  if (L.Cout <= 32) return TG_128x32;
+  if (M <= 32) return TG_32x128;
+  if (M <= 64) return TG_64x64;
+  return TG_128x128;
+}
+
+void build_schedule(const ian_handle* h, const TgLayer& L, int nimg, Schedule& S) {
+  const int M = nimg * L.QH * L.QW;
+  S.cfg = pick_config(h, L, M);
+  const TgShape sh = tg_shape(S.cfg);
+  const int tiles_m = (M + sh.bm - 1) / sh.bm;
+  const int tiles_n = (L.Cout + sh.bn - 1) / sh.bn;
+  const int kpt = L.Cin / 32;
+  const int ncls = (int)L.classes.size();
+  long long total_steps = 0;
+  int total_tiles = 0;
+  for (auto& c : L.classes) {
+    total_steps += (long long)tiles_m * tiles_n * c.ntaps * kpt;
+    total_tiles += tiles_m * tiles_n;
+  }
+  int steps_per_item = 1 << 30;
+  bool split = false;
+  if (h->opt.tg_split && total_tiles < h->opt.tg_no_split_items) {
+    long long spi = (total_steps + h->opt.tg_target_items - 1) / h->opt.tg_target_items;
+    steps_per_item = (int)std::max<long long>(spi, h->opt.tg_min_steps);
+    for (auto& c : L.classes)
+      if (c.ntaps * kpt > steps_per_item) split = true;
+  }
+  struct Group {
+    std::vector<TgItem> items;
+    int weight;
+  };
+  std::vector<Group> groups;
+  int gm = std::max(1, h->opt.tg_xcd_group), gn = std::max(1, h->opt.tg_xcd_group);
+  S.h_tiles.clear();
+  size_t slab_next = 0;
+  // tile -> slab bookkeeping
+  std::vector<std::vector<int>> nsplit_c(ncls);
+  for (int c = 0; c < ncls; ++c) {
+    const int ksteps = L.classes[c].ntaps * kpt;
+    int ns = 1;
+    if (split) ns = std::max(1, (ksteps + steps_per_item - 1) / steps_per_item);
+    const int per = (ksteps + ns - 1) / ns;
+    ns = (ksteps + per - 1) / per;
+    // slab indices: tile-major so that the reduce pass reads contiguous slabs
+    std::vector<int> slab0((size_t)tiles_m * tiles_n, -1);
+    if (split) {
+      for (int mt = 0; mt < tiles_m; ++mt)
+        for (int nt = 0; nt < tiles_n; ++nt) {
+          slab0[(size_t)mt * tiles_n + nt] = (int)slab_next;
+          TgTile t{c, mt * sh.bm, nt * sh.bn, (int)slab_next, ns, 0, 0, 0};
+          S.h_tiles.push_back(t);
+          slab_next += ns;
+        }
+    }
+    for (int s = 0; s < ns; ++s) {
+      const int k0 = s * per, k1 = std::min(ksteps, (s + 1) * per);
+      for (int nb = 0; nb < tiles_n; nb += gn)
+        for (int mb = 0; mb < tiles_m; mb += gm) {
+          Group g;
+          g.weight = k1 - k0;
+          for (int nt = nb; nt < std::min(tiles_n, nb + gn); ++nt)
+            for (int mt = mb; mt < std::min(tiles_m, mb + gm); ++mt) {
+              TgItem it{c, mt * sh.bm, nt * sh.bn, k0, k1, split ? slab0[(size_t)mt * tiles_n + nt] + s : -1, 0, 0};
+              g.items.push_back(it);
+            }
+          groups.push_back(std::move(g));
+        }
+    }
+  }
+  std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) { return a.weight > b.weight; });
+  // deal supergroups to the 8 XCDs (block b runs on XCD b%8): always to the least-loaded list
+  std::vector<std::vector<TgItem>> lists(8);
+  std::vector<long long> load(8, 0);
+  for (auto& g : groups) {
+    int best = 0;
+    for (int x = 1; x < 8; ++x)
+      if (load[x] < load[best]) best = x;
+    for (auto& it : g.items) lists[best].push_back(it);
+    load[best] += (long long)g.weight * g.items.size();
+  }
+  size_t longest = 0;
+  for (auto& l : lists) longest = std::max(longest, l.size());
+  S.h_items.clear();
+  const TgItem empty{0, 0, 0, 0, 0, -1, 0, 0};
+  for (size_t k = 0; k < longest; ++k)
+    for (int x = 0; x < 8; ++x) S.h_items.push_back(k < lists[x].size() ? lists[x][k] : empty);
+  while (!S.h_items.empty() && S.h_items.back().ks0 >= S.h_items.back().ks1) S.h_items.pop_back();
+  S.nitems = (int)S.h_items.size();
+  S.ntiles = split ? (int)S.h_tiles.size() : 0;
+  S.slab_tiles = slab_next;
+}
+
+int get_schedule(ian_handle* h, TgLayer& L, int nimg, Schedule** out) {
+  auto it = L.sched.find(nimg);
+  if (it == L.sched.end()) {
+    Schedule S;
+    build_schedule(h, L, nimg, S);
+    int rc;
+    if ((rc = upload(h, S.h_items, &S.d_items))) return rc;
+    if ((rc = upload(h, S.h_tiles, &S.d_tiles))) return rc;
+    const TgShape sh = tg_shape(S.cfg);
+    const size_t need = S.slab_tiles * sh.bm * sh.bn;
+    if (need > h->slab_cap) {
+      if (h->d_slab) HIPCHK(h, hipFree(h->d_slab));
+      HIPCHK(h, hipMalloc((void**)&h->d_slab, need * sizeof(float)));
+      h->slab_cap = need;
+    }
+    it = L.sched.emplace(nimg, std::move(S)).first;
+  }
+  *out = &it->second;
+  return 0;
+}
+
+void free_schedules(TgLayer& L) {
+  for (auto& kv : L.sched) {
+    if (kv.second.d_items) (void)hipFree(kv.second.d_items);
+    if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
+  }
+  L.sched.clear();
+}
+
+int ensure_slot(ian_handle* h, int slot, int n, bool grad = false) {
+  Slot& s = h->slots[slot];
+  const size_t need = s.per_image() * (size_t)n;
+  float*& ptr = grad ? s.g : s.d;
+  size_t& cap = grad ? s.gcap : s.cap;
+  if (need > cap) {
+    if (ptr) HIPCHK(h, hipFree(ptr));
+    HIPCHK(h, hipMalloc((void**)&ptr, need * sizeof(float)));
+    HIPCHK(h, hipMemset(ptr, 0, need * sizeof(float)));  // channel padding must stay zero
+    cap = need;
+  }
+  return 0;
+}
+
+bool is_device_ptr(const void* p) {
+  hipPointerAttribute_t a;
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+int run_tapgemm(ian_handle* h, TgLayer& L, int nimg, const float* x, float* y, int y_stride, const TgEpilogue& epi,
+                hipStream_t st) {
+  Schedule* S;
+  int rc = get_schedule(h, L, nimg, &S);
+  if (rc) return rc;
+  TgParams p;
+  p.x = x; p.w = L.d_w; p.y = y; p.slab = h->d_slab;
+  p.items = S->d_items; p.classes = L.d_classes; p.taps = L.d_taps;
+  p.epi = epi;
+  p.M = nimg * L.QH * L.QW;
+  p.IH = L.IH; p.IW = L.IW; p.Cin = L.Cin;
+  p.qw_shift = ilog2_exact(L.QW); p.qhw_shift = ilog2_exact(L.QH * L.QW);
+  p.si = L.si; p.by = L.by; p.bx = L.bx; p.so = L.so;
+  p.OH = L.OH; p.OW = L.OW; p.Cout = L.Cout; p.y_stride = y_stride; p.CoutPad = L.CoutPad;
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  if (h->prof) {
+    if (h->ev_used == h->ev_pool.size()) {
+      hipEvent_t a, b;
+      HIPCHK(h, hipEventCreate(&a));
+      HIPCHK(h, hipEventCreate(&b));
+      h->ev_pool.push_back({a, b});
+    }
+    ev = &h->ev_pool[h->ev_used++];
+    HIPCHK(h, hipEventRecord(ev->first, st));
+  }
+  HIPCHK(h, launch_tapgemm(S->cfg, p, S->nitems, st));
+  if (S->ntiles > 0) {
+    TgReduceParams r;
+    r.slab = h->d_slab; r.y = y; r.tiles = S->d_tiles; r.classes = L.d_classes; r.epi = epi;
+    r.M = p.M; r.qw_shift = p.qw_shift; r.qhw_shift = p.qhw_shift; r.so = L.so; r.OH = L.OH; r.OW = L.OW;
+    r.Cout = L.Cout; r.y_stride = y_stride;
+    HIPCHK(h, launch_tapgemm_reduce(S->cfg, r, S->ntiles, st));
+  }
+  if (ev) {
+    HIPCHK(h, hipEventRecord(ev->second, st));
+    h->prof_flops += 2.0 * L.macs_per_image() * nimg;
+    h->prof_launches += 1;
+  }
+  return 0;
+}
+
+TgEpilogue fwd_epi(const OpPlan& op, const float* res) {
+  TgEpilogue e;
+  e.scale = op.d_scale; e.shift = op.d_shift; e.res = res; e.yfwd = nullptr; e.act = op.d.act; e.mode = TG_EPI_FWD;
+  return e;
+}
+
+// ----- forward executor ---------------------------------------------------------------------------------
+int run_op_fwd(ian_handle* h, OpPlan& op, int n, hipStream_t st) {
+  Slot& src = h->slots[op.d.src];
+  Slot& dst = h->slots[op.d.dst];
+  int rc;
+  if ((rc = ensure_slot(h, op.d.dst, n))) return rc;
+  const float* res = nullptr;
+  switch (op.d.kind) {
+    case IAN_OP_CONV5S2:
+      if (op.edge) {
+        HIPCHK(h, launch_conv1_nchw(src.d, op.d_edge_w, op.d_scale, op.d_shift, dst.d, n, op.d.in_h, op.d.in_w,
+                                    op.d.cout, op.d.act, st));
+        return 0;
+      }
+      return run_tapgemm(h, op.fwd, n, src.d, dst.d, dst.cs, fwd_epi(op, nullptr), st);
+    case IAN_OP_DECONV5S2:
+      if (op.edge) {
+        HIPCHK(h, launch_deconv_out_nchw(src.d, op.d_edge_w, op.d_scale, op.d_shift, dst.d, n, op.d.in_h, op.d.in_w,
+                                         src.cs, op.d.cout, op.d.act, st));
+        return 0;
+      }
+      return run_tapgemm(h, op.fwd, n, src.d, dst.d, dst.cs, fwd_epi(op, nullptr), st);
+    case IAN_OP_MDC3:
+      if (op.d.src2 >= 0) res = h->slots[op.d.src2].d;
+      return run_tapgemm(h, op.fwd, n, src.d, dst.d, dst.cs, fwd_epi(op, res), st);
+    case IAN_OP_DENSE:
+      return run_tapgemm(h, op.fwd, n, src.d, dst.d, (int)dst.per_image(), fwd_epi(op, nullptr), st);
+    case IAN_OP_AFFINE:
+      HIPCHK(h, launch_affine(src.d, dst.d, op.d_scale, op.d_shift, (long long)n * src.h * src.w, src.c, src.cs,
+                              op.d.act, st));
+      return 0;
+    case IAN_OP_MADE_IAF:
+      HIPCHK(h, launch_made_iaf(src.d, dst.d, op.d_made_w, op.d_made_b, n, op.d.cin, src.cs, st));
+      return 0;
+    case IAN_OP_BETA:
+      HIPCHK(h, launch_beta(src.d, h->slots[op.d.src2].d, h->slots[op.d.src3].d, dst.d, n, src.h * src.w, src.cs, st));
+      return 0;
+    case IAN_OP_CONCAT: {
+      Slot& b = h->slots[op.d.src2];
+      HIPCHK(h, launch_concat2(src.d, src.c, src.cs, b.d, b.c, b.cs, dst.d, dst.cs, (long long)n * src.h * src.w, st));
+      return 0;
+    }
+  }
+  return fail(h, -5, "unknown op kind %d", op.d.kind);
+}
+
+int run_segment(ian_handle* h, int seg, int n, hipStream_t st) {
+  for (auto& op : h->ops)
+    if (op.d.segment == seg) {
+      int rc = run_op_fwd(h, op, n, st);
+      if (rc) return rc;
+    }
+  return 0;
+}
+
+// stage a caller buffer (host or device) into a device pointer; returns pointer to use
+int stage_in(ian_handle* h, const float* src, size_t count, float** buf, size_t* cap, const float** out,
+             hipStream_t st) {
+  if (is_device_ptr(src)) {
+    *out = src;
+    return 0;
+  }
+  if (count > *cap) {
+    if (*buf) HIPCHK(h, hipFree(*buf));
+    HIPCHK(h, hipMalloc((void**)buf, count * sizeof(float)));
+    *cap = count;
+  }
+  HIPCHK(h, hipMemcpyAsync(*buf, src, count * sizeof(float), hipMemcpyHostToDevice, st));
+  *out = *buf;
+  return 0;
+}
+
+int set_image_input(ian_handle* h, const float* x, int n, hipStream_t st) {
+  Slot& xs = h->slots[h->desc.x_slot];
+  const size_t count = xs.per_image() * (size_t)n;
+  int rc;
+  if ((rc = ensure_slot(h, h->desc.x_slot, n))) return rc;
+  HIPCHK(h, hipMemcpyAsync(xs.d, x, count * sizeof(float), is_device_ptr(x) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  return 0;
+}
+
+int set_latent_input(ian_handle* h, int slot, const float* z, int n, hipStream_t st) {
+  Slot& zs = h->slots[slot];
+  int rc;
+  if ((rc = ensure_slot(h, slot, n))) return rc;
+  const float* dz;
+  if ((rc = stage_in(h, z, (size_t)n * zs.c, &h->d_stage_in, &h->stage_in_cap, &dz, st))) return rc;
+  HIPCHK(h, launch_rows_copy(dz, zs.c, zs.d, zs.cs, n, zs.c, st));
+  return 0;
+}
+
+int get_latent_output(ian_handle* h, int slot, float* z, int n, hipStream_t st) {
+  Slot& zs = h->slots[slot];
+  if (is_device_ptr(z)) {
+    HIPCHK(h, launch_rows_copy(zs.d, zs.cs, z, zs.c, n, zs.c, st));
+    return 0;
+  }
+  const size_t count = (size_t)n * zs.c;
+  if (count > h->stage_out_cap) {
+    if (h->d_stage_out) HIPCHK(h, hipFree(h->d_stage_out));
+    HIPCHK(h, hipMalloc((void**)&h->d_stage_out, count * sizeof(float)));
+    h->stage_out_cap = count;
+  }
+  HIPCHK(h, launch_rows_copy(zs.d, zs.cs, h->d_stage_out, zs.c, n, zs.c, st));
+  HIPCHK(h, hipMemcpyAsync(z, h->d_stage_out, count * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  return 0;
+}
+
+int get_image_output(ian_handle* h, float* x, int n, hipStream_t st) {
+  Slot& os = h->slots[h->desc.out_slot];
+  const size_t count = os.per_image() * (size_t)n;
+  const bool dev = is_device_ptr(x);
+  HIPCHK(h, hipMemcpyAsync(x, os.d, count * sizeof(float), dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+  if (!dev) HIPCHK(h, hipStreamSynchronize(st));
+  return 0;
+}
+
+int check_ready(ian_handle* h, int n) {
+  if (!h) return -1;
+  if (!h->finalized) return fail(h, -6, "ian_finalize has not been called");
+  if (n <= 0) return fail(h, -7, "batch size must be positive (got %d)", n);
+  return 0;
+}
+
+struct TotalTimer {  // whole-call device time when profiling
+  ian_handle* h;
+  hipStream_t st;
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  TotalTimer(ian_handle* h_, hipStream_t s) : h(h_), st(s) {
+    if (!h->prof) return;
+    if (h->ev_total_used == h->ev_total.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      h->ev_total.push_back({a, b});
+    }
+    ev = &h->ev_total[h->ev_total_used++];
+    (void)hipEventRecord(ev->first, st);
+  }
+  ~TotalTimer() {
+    if (ev) (void)hipEventRecord(ev->second, st);
+  }
+};
+
+// ----- latent-brush backward (API.py:59,64): reverse sweep over the decoder ops --------------------------
+// Gradient buffers hold dL/d(pre-epilogue value) of the slot's producer, so each backward tapgemm's epilogue
+// (TG_EPI_BWD) multiplies by act'(y)*scale of the NEXT producer upstream and no separate elementwise pass runs.
+int run_decoder_backward(ian_handle* h, int mode, int c1, int r1, int c2, int r2, const float* d_rgb, hipStream_t st) {
+  std::vector<OpPlan*> dec;
+  for (auto& op : h->ops)
+    if (op.d.segment == IAN_SEG_DEC) dec.push_back(&op);
+  if (dec.empty()) return fail(h, -8, "no decoder ops");
+  // supported graph: a single chain DENSE -> DECONV5S2* -> DECONV5S2(edge) (IAN_simple decoder)
+  for (size_t i = 0; i < dec.size(); ++i) {
+    const int k = dec[i]->d.kind;
+    const bool ok = (k == IAN_OP_DENSE || k == IAN_OP_DECONV5S2) && dec[i]->d.src2 < 0 &&
+                    (i == 0 || dec[i]->d.src == dec[i - 1]->d.dst);
+    if (!ok) return fail(h, -9, "imgrad: backward is implemented for DENSE/DECONV5S2 chains only (op '%s')", dec[i]->name.c_str());
+  }
+  OpPlan& last = *dec.back();
+  Slot& out = h->slots[last.d.dst];
+  const int H = out.h, W = out.w;
+  if (!(last.d.kind == IAN_OP_DECONV5S2 && last.edge)) return fail(h, -9, "imgrad: last decoder op must be the image deconv");
+  if (c1 < 0 || r1 < 0 || c2 > W || r2 > H) return fail(h, -7, "patch (%d,%d,%d,%d) outside the %dx%d image", c1, r1, c2, r2, W, H);
+  if (!h->d_gseed) HIPCHK(h, hipMalloc((void**)&h->d_gseed, (size_t)3 * H * W * sizeof(float)));
+  HIPCHK(h, launch_patch_seed(out.d, d_rgb, h->d_gseed, H, W, c1, r1, c2, r2, mode, st));
+  // gradient wrt dec_out's pre-activation
+  HIPCHK(h, launch_dact_nchw(h->d_gseed, out.d, last.d_scale, 1, out.c, H * W, last.d.act, st));
+  // dec_out backward -> gradient wrt pre-epilogue value of the previous op
+  for (int i = (int)dec.size() - 1; i >= 0; --i) {
+    OpPlan& op = *dec[i];
+    Slot& in = h->slots[op.d.src];
+    int rc;
+    if ((rc = ensure_slot(h, op.d.src, 1, true))) return rc;
+    OpPlan* prev = i > 0 ? dec[i - 1] : nullptr;
+    TgEpilogue e;
+    e.scale = prev ? prev->d_scale : nullptr;
+    e.shift = nullptr; e.res = nullptr;
+    e.yfwd = prev ? in.d : nullptr;
+    e.act = prev ? prev->d.act : IAN_ACT_NONE;
+    e.mode = TG_EPI_BWD;
+    if (op.edge) {
+      HIPCHK(h, launch_deconv_out_bwd(h->d_gseed, op.d_edge_w, in.g, e.yfwd, e.scale, 1, op.d.in_h, op.d.in_w, in.cs,
+                                      op.d.cout, e.act, st));
+    } else {
+      Slot& o = h->slots[op.d.dst];
+      const int ystride = (op.d.kind == IAN_OP_DENSE) ? (int)in.per_image() : in.cs;
+      if ((rc = run_tapgemm(h, op.bwd, 1, o.g, in.g, ystride, e, st))) return rc;
+    }
+  }
+  return 0;
+}
+
+int grad_common(ian_handle* h, int mode, int c1, int r1, int c2, int r2, const float* rgb, const float* z, float* dz,
+                void* stream) {
+  int rc = check_ready(h, 1);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  TotalTimer tt(h, st);
+  if ((rc = set_latent_input(h, h->desc.z_slot, z, 1, st))) return rc;
+  if ((rc = run_segment(h, IAN_SEG_DEC, 1, st))) return rc;
+  const float* d_rgb = nullptr;
+  if (mode == 1) {
+    Slot& out = h->slots[h->desc.out_slot];
+    const size_t cnt = out.per_image();
+    if (is_device_ptr(rgb)) d_rgb = rgb;
+    else {
+      if (!h->d_rgb) HIPCHK(h, hipMalloc((void**)&h->d_rgb, cnt * sizeof(float)));
+      HIPCHK(h, hipMemcpyAsync(h->d_rgb, rgb, cnt * sizeof(float), hipMemcpyHostToDevice, st));
+      d_rgb = h->d_rgb;
+    }
+  }
+  if ((rc = run_decoder_backward(h, mode, c1, r1, c2, r2, d_rgb, st))) return rc;
+  // result sits in the gradient buffer of the z slot
+  Slot& zs = h->slots[h->desc.z_slot];
+  if (is_device_ptr(dz)) {
+    HIPCHK(h, launch_rows_copy(zs.g, zs.cs, dz, zs.c, 1, zs.c, st));
+  } else {
+    if ((size_t)zs.c > h->stage_out_cap) {
+      if (h->d_stage_out) HIPCHK(h, hipFree(h->d_stage_out));
+      HIPCHK(h, hipMalloc((void**)&h->d_stage_out, zs.c * sizeof(float)));
+      h->stage_out_cap = zs.c;
+    }
+    HIPCHK(h, launch_rows_copy(zs.g, zs.cs, h->d_stage_out, zs.c, 1, zs.c, st));
+    HIPCHK(h, hipMemcpyAsync(dz, h->d_stage_out, zs.c * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+  }
+  return 0;
+}
+
+}  // namespace
+
+// =========================================== C ABI ====================================================
+extern "C" {
+
+const char* ian_version(void) { return "libian 0.1 (gfx950)"; }
+
+const char* ian_last_error(ian_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int ian_create(const ian_model_desc* desc, ian_handle** out) {
+  if (!desc || !out) return -1;
+  std::unique_ptr<ian_handle> h(new ian_handle());
+  h->desc = *desc;
+  h->strings.reserve((size_t)desc->n_ops * 2 + 4);
+  h->ops.resize(desc->n_ops);
+  for (int i = 0; i < desc->n_ops; ++i) {
+    OpPlan& op = h->ops[i];
+    op.d = desc->ops[i];
+    op.name = op.d.name ? op.d.name : "";
+    op.bn_name = op.d.bn_name ? op.d.bn_name : "";
+    op.d.name = nullptr;
+    op.d.bn_name = nullptr;
+    if (op.d.n_scales < 0 || op.d.n_scales > IAN_MAX_SCALES) return -1;
+    auto bad = [&](int s) { return s < -1 || s >= desc->n_slots; };
+    if (bad(op.d.src) || bad(op.d.src2) || bad(op.d.src3) || bad(op.d.dst) || op.d.src < 0 || op.d.dst < 0) return -1;
+  }
+  h->slots.resize(desc->n_slots);
+  for (int i = 0; i < desc->n_slots; ++i) {
+    Slot& s = h->slots[i];
+    s.h = desc->slots[i].h; s.w = desc->slots[i].w; s.c = desc->slots[i].c;
+    s.cs = round_up(s.c, 32);
+    s.nchw = (i == desc->x_slot || i == desc->out_slot);
+  }
+  h->desc.ops = nullptr;
+  h->desc.slots = nullptr;
+  *out = h.release();
+  return 0;
+}
+
+int ian_load_param(ian_handle* h, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+  if (!h || !name || !data || ndim < 0 || ndim > 8) return fail(h, -1, "bad argument to ian_load_param");
+  if (h->finalized) return fail(h, -6, "model already finalized");
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  const int64_t n = t.numel();
+  t.data.assign(data, data + n);
+  h->params[name] = std::move(t);
+  return 0;
+}
+
+int ian_set_made_masks(ian_handle* h, const float* m0, const float* m1, const float* md, int32_t n) {
+  if (!h || !m0 || !m1 || !md || n <= 0) return fail(h, -1, "bad argument to ian_set_made_masks");
+  const float* src[3] = {m0, m1, md};
+  for (int k = 0; k < 3; ++k) {
+    h->made_masks[k].assign(src[k], src[k] + (size_t)n * n);
+    for (float v : h->made_masks[k])
+      if (v != 0.f && v != 1.f) return fail(h, -3, "MADE mask %d is not 0/1 valued", k);
+  }
+  h->made_n = n;
+  return 0;
+}
+
+int ian_finalize(ian_handle* h) {
+  if (!h) return -1;
+  if (h->finalized) return fail(h, -6, "model already finalized");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return fail(h, -10, "no HIP device available: libian has no CPU fallback");
+  }
+  for (auto& op : h->ops) {
+    int rc = 0;
+    std::vector<int> out_perm;
+    bool has_out_perm = false;
+    switch (op.d.kind) {
+      case IAN_OP_CONV5S2:
+        if ((rc = pack_conv_fwd(h, op))) return rc;
+        if ((rc = build_affine(h, op, op.d.cout, nullptr))) return rc;
+        break;
+      case IAN_OP_DECONV5S2:
+        if ((rc = pack_deconv(h, op))) return rc;
+        if ((rc = build_affine(h, op, op.d.cout, nullptr))) return rc;
+        break;
+      case IAN_OP_MDC3:
+        if ((rc = pack_mdc(h, op))) return rc;
+        if ((rc = build_affine(h, op, op.d.cout, nullptr))) return rc;
+        break;
+      case IAN_OP_DENSE:
+        if ((rc = pack_dense(h, op, out_perm, has_out_perm))) return rc;
+        if ((rc = build_affine(h, op, op.d.cout, has_out_perm ? &out_perm : nullptr))) return rc;
+        break;
+      case IAN_OP_AFFINE:
+        if ((rc = build_affine(h, op, op.d.cout, nullptr))) return rc;
+        break;
+      case IAN_OP_MADE_IAF:
+        if ((rc = pack_made(h, op))) return rc;
+        break;
+      case IAN_OP_BETA:
+      case IAN_OP_CONCAT:
+        break;
+      default:
+        return fail(h, -5, "unknown op kind %d", op.d.kind);
+    }
+    if ((rc = upload_layer(h, op.fwd))) return rc;
+    if ((rc = upload_layer(h, op.bwd))) return rc;
+    if ((rc = upload(h, op.h_edge_w, &op.d_edge_w))) return rc;
+    if ((rc = upload(h, op.h_scale, &op.d_scale))) return rc;
+    if ((rc = upload(h, op.h_shift, &op.d_shift))) return rc;
+    std::vector<float>().swap(op.h_edge_w);
+  }
+  h->params.clear();
+  h->finalized = true;
+  return 0;
+}
+
+int ian_encode_pre_iaf(ian_handle* h, const float* x, int32_t n, float* z, void* stream) {
+  int rc = check_ready(h, n);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  TotalTimer tt(h, st);
+  if ((rc = set_image_input(h, x, n, st))) return rc;
+  if ((rc = run_segment(h, IAN_SEG_ENC, n, st))) return rc;
+  return get_latent_output(h, h->desc.zpre_slot, z, n, st);
+}
+
+int ian_encode(ian_handle* h, const float* x, int32_t n, float* z, void* stream) {
+  int rc = check_ready(h, n);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  TotalTimer tt(h, st);
+  if ((rc = set_image_input(h, x, n, st))) return rc;
+  if ((rc = run_segment(h, IAN_SEG_ENC, n, st))) return rc;
+  if ((rc = run_segment(h, IAN_SEG_IAF, n, st))) return rc;
+  return get_latent_output(h, h->desc.z_slot, z, n, st);
+}
+
+int ian_iaf(ian_handle* h, const float* zpre, int32_t n, float* z, void* stream) {
+  int rc = check_ready(h, n);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if ((rc = set_latent_input(h, h->desc.zpre_slot, zpre, n, st))) return rc;
+  if ((rc = run_segment(h, IAN_SEG_IAF, n, st))) return rc;
+  return get_latent_output(h, h->desc.z_slot, z, n, st);
+}
+
+int ian_decode(ian_handle* h, const float* z, int32_t n, float* x, void* stream) {
+  int rc = check_ready(h, n);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  TotalTimer tt(h, st);
+  if ((rc = set_latent_input(h, h->desc.z_slot, z, n, st))) return rc;
+  if ((rc = run_segment(h, IAN_SEG_DEC, n, st))) return rc;
+  return get_image_output(h, x, n, st);
+}
+
+int ian_reconstruct(ian_handle* h, const float* x, int32_t n, float* xhat, void* stream) {
+  int rc = check_ready(h, n);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  TotalTimer tt(h, st);
+  if ((rc = set_image_input(h, x, n, st))) return rc;
+  if ((rc = run_segment(h, IAN_SEG_ENC, n, st))) return rc;
+  if ((rc = run_segment(h, IAN_SEG_IAF, n, st))) return rc;
+  if ((rc = run_segment(h, IAN_SEG_DEC, n, st))) return rc;
+  return get_image_output(h, xhat, n, st);
+}
+
+int ian_grad_rgb(ian_handle* h, int32_t c1, int32_t r1, int32_t c2, int32_t r2, const float* rgb, const float* z,
+                 float* dz, void* stream) {
+  if (!rgb) return fail(h, -1, "rgb is null");
+  return grad_common(h, 1, c1, r1, c2, r2, rgb, z, dz, stream);
+}
+
+int ian_grad_light(ian_handle* h, int32_t c1, int32_t r1, int32_t c2, int32_t r2, const float* z, float* dz,
+                   void* stream) {
+  return grad_common(h, 0, c1, r1, c2, r2, nullptr, z, dz, stream);
+}
+
+int ian_read_slot(ian_handle* h, int32_t slot, int32_t n, float* out, void* stream) {
+  int rc = check_ready(h, n);
+  if (rc) return rc;
+  if (slot < 0 || slot >= (int)h->slots.size()) return fail(h, -1, "bad slot %d", slot);
+  hipStream_t st = (hipStream_t)stream;
+  Slot& s = h->slots[slot];
+  if (!s.d || s.cap < s.per_image() * (size_t)n) return fail(h, -1, "slot %d holds no activation for batch %d", slot, n);
+  const size_t count = (size_t)n * s.c * s.h * s.w;
+  const bool dev = is_device_ptr(out);
+  float* tmp = nullptr;
+  float* target = out;
+  if (!dev) {
+    HIPCHK(h, hipMalloc((void**)&tmp, count * sizeof(float)));
+    target = tmp;
+  }
+  if (s.nchw) HIPCHK(h, hipMemcpyAsync(target, s.d, count * sizeof(float), hipMemcpyDeviceToDevice, st));
+  else HIPCHK(h, launch_nhwc_to_nchw(s.d, s.cs, target, n, s.h * s.w, s.c, st));
+  if (!dev) {
+    HIPCHK(h, hipMemcpyAsync(out, tmp, count * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipFree(tmp));
+  }
+  return 0;
+}
+
+int ian_profile_enable(ian_handle* h, int32_t on) {
+  if (!h) return -1;
+  h->prof = on != 0;
+  h->ev_used = 0;
+  h->ev_total_used = 0;
+  h->prof_flops = 0;
+  h->prof_launches = 0;
+  return 0;
+}
+
+int ian_profile_read(ian_handle* h, double* tapgemm_ms, int64_t* tapgemm_launches, double* tapgemm_flops,
+                     double* total_ms) {
+  if (!h) return -1;
+  HIPCHK(h, hipDeviceSynchronize());
+  double ms = 0;
+  for (size_t i = 0; i < h->ev_used; ++i) {
+    float t = 0;
+    HIPCHK(h, hipEventElapsedTime(&t, h->ev_pool[i].first, h->ev_pool[i].second));
+    ms += t;
+  }
+  double tot = 0;
+  for (size_t i = 0; i < h->ev_total_used; ++i) {
+    float t = 0;
+    HIPCHK(h, hipEventElapsedTime(&t, h->ev_total[i].first, h->ev_total[i].second));
+    tot += t;
+  }
+  if (tapgemm_ms) *tapgemm_ms = ms;
+  if (tapgemm_launches) *tapgemm_launches = h->prof_launches;
+  if (tapgemm_flops) *tapgemm_flops = h->prof_flops;
+  if (total_ms) *total_ms = tot;
+  return 0;
+}
+
+int ian_set_option(ian_handle* h, const char* key, int32_t value) {
+  if (!h || !key) return -1;
+  const std::string k(key);
+  if (k == "tg_cfg") h->opt.tg_cfg = value;
+  else if (k == "tg_target_items") h->opt.tg_target_items = std::max(1, value);
+  else if (k == "tg_min_steps") h->opt.tg_min_steps = std::max(1, value);
+  else if (k == "tg_no_split_items") h->opt.tg_no_split_items = value;
+  else if (k == "tg_split") h->opt.tg_split = value;
+  else if (k == "tg_xcd_group") h->opt.tg_xcd_group = std::max(1, value);
+  else return fail(h, -1, "unknown option '%s'", key);
+  for (auto& op : h->ops) {  // schedules depend on the options
+    free_schedules(op.fwd);
+    free_schedules(op.bwd);
+  }
+  return 0;
+}
+
+void ian_destroy(ian_handle* h) {
+  if (!h) return;
+  for (auto& op : h->ops) {
+    free_schedules(op.fwd);
+    free_schedules(op.bwd);
+    for (TgLayer* L : {&op.fwd, &op.bwd}) {
+      if (L->d_w) (void)hipFree(L->d_w);
+      if (L->d_classes) (void)hipFree(L->d_classes);
+      if (L->d_taps) (void)hipFree(L->d_taps);
+    }
+    for (float* p : {op.d_edge_w, op.d_scale, op.d_shift, op.d_made_w, op.d_made_b})
+      if (p) (void)hipFree(p);
+  }
+  for (auto& s : h->slots) {
+    if (s.d) (void)hipFree(s.d);
+    if (s.g) (void)hipFree(s.g);
+  }
+  for (float* p : {h->d_slab, h->d_stage_in, h->d_stage_out, h->d_gseed, h->d_rgb})
+    if (p) (void)hipFree(p);
+  for (auto& e : h->ev_pool) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  for (auto& e : h->ev_total) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  delete h;
+}
+
+}  // extern "C"
