@@ -135,6 +135,9 @@ int ian_grad_light(ian_handle* h, int32_t c1, int32_t r1, int32_t c2, int32_t r2
 /* Introspection used by tests, bench.py and profiling (not part of the reference surface). */
 /* Copy the activation of tensor slot `slot` from the last call, converted to NCHW, into out (host or device). */
 int ian_read_slot(ian_handle* h, int32_t slot, int32_t n, float* out, void* stream);
+/* Same for the gradient buffer the last ian_grad_* call left in `slot`: d loss / d (pre-epilogue value of the
+   slot's producer), i.e. before batch-norm scale and activation (NCHW). */
+int ian_read_slot_grad(ian_handle* h, int32_t slot, int32_t n, float* out, void* stream);
 /* Name and accumulated device time (ms, HIP events on `stream`) of the dominant kernel family since the last reset. */
 int ian_profile_enable(ian_handle* h, int32_t on);
 int ian_profile_read(ian_handle* h, double* tapgemm_ms, int64_t* tapgemm_launches, double* tapgemm_flops,

@@ -38,6 +38,8 @@ struct TgEpilogue {
   const float* res;    // residual tensor, same layout as y, added before the affine; or nullptr
   const float* yfwd;   // BWD: forward output of the layer whose pre-activation gradient is produced
   int act;             // enum ian_act
+  int scale_period;    // 0: scale/shift indexed by channel; >0: by (element offset % period) -- per-feature
+                       // batch-norm of a dense layer whose output is viewed as an NHWC map (IAN_simple.py:129-139)
   int mode;            // TG_EPI_FWD: y = act((acc+res)*scale+shift)
                        // TG_EPI_BWD: y = (acc [+res]) * act'(yfwd) * scale   (gradient wrt pre-affine value)
 };

@@ -675,6 +675,7 @@ int run_tapgemm(ian_handle* h, TgLayer& L, int nimg, const float* x, float* y, i
 TgEpilogue fwd_epi(const OpPlan& op, const float* res) {
   TgEpilogue e;
   e.scale = op.d_scale; e.shift = op.d_shift; e.res = res; e.yfwd = nullptr; e.act = op.d.act; e.mode = TG_EPI_FWD;
+  e.scale_period = 0;
   return e;
 }
 
@@ -859,6 +860,8 @@ int run_decoder_backward(ian_handle* h, int mode, int c1, int r1, int c2, int r2
     e.yfwd = prev ? in.d : nullptr;
     e.act = prev ? prev->d.act : IAN_ACT_NONE;
     e.mode = TG_EPI_BWD;
+    // a dense producer's batch-norm is per feature = per (pixel, channel) of the map it is reshaped to
+    e.scale_period = (prev && prev->d.kind == IAN_OP_DENSE && in.h * in.w > 1) ? (int)in.per_image() : 0;
     if (op.edge) {
       HIPCHK(h, launch_deconv_out_bwd(h->d_gseed, op.d_edge_w, in.g, e.yfwd, e.scale, 1, op.d.in_h, op.d.in_w, in.cs,
                                       op.d.cout, e.act, st));
@@ -1086,13 +1089,18 @@ int ian_grad_light(ian_handle* h, int32_t c1, int32_t r1, int32_t c2, int32_t r2
   return grad_common(h, 0, c1, r1, c2, r2, nullptr, z, dz, stream);
 }
 
-int ian_read_slot(ian_handle* h, int32_t slot, int32_t n, float* out, void* stream) {
+static int read_slot_impl(ian_handle* h, int32_t slot, int32_t n, float* out, void* stream, bool grad) {
   int rc = check_ready(h, n);
   if (rc) return rc;
   if (slot < 0 || slot >= (int)h->slots.size()) return fail(h, -1, "bad slot %d", slot);
   hipStream_t st = (hipStream_t)stream;
-  Slot& s = h->slots[slot];
-  if (!s.d || s.cap < s.per_image() * (size_t)n) return fail(h, -1, "slot %d holds no activation for batch %d", slot, n);
+  Slot s = h->slots[slot];
+  if (grad) {
+    s.d = s.g;
+    s.cap = s.gcap;
+    s.nchw = false;
+  }
+  if (!s.d || s.cap < s.per_image() * (size_t)n) return fail(h, -1, "slot %d holds no %s for batch %d", slot, grad ? "gradient" : "activation", n);
   const size_t count = (size_t)n * s.c * s.h * s.w;
   const bool dev = is_device_ptr(out);
   float* tmp = nullptr;
@@ -1109,6 +1117,14 @@ int ian_read_slot(ian_handle* h, int32_t slot, int32_t n, float* out, void* stre
     HIPCHK(h, hipFree(tmp));
   }
   return 0;
+}
+
+int ian_read_slot(ian_handle* h, int32_t slot, int32_t n, float* out, void* stream) {
+  return read_slot_impl(h, slot, n, out, stream, false);
+}
+
+int ian_read_slot_grad(ian_handle* h, int32_t slot, int32_t n, float* out, void* stream) {
+  return read_slot_impl(h, slot, n, out, stream, true);
 }
 
 int ian_profile_enable(ian_handle* h, int32_t on) {

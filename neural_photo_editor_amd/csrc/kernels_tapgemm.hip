@@ -49,9 +49,10 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {
 
 __device__ __forceinline__ float epilogue_value(const TgEpilogue& e, float acc, size_t yoff, int c) {
   if (e.res) acc += e.res[yoff];
-  const float sc = e.scale ? e.scale[c] : 1.f;
+  const int si = e.scale_period ? (int)(yoff % (size_t)e.scale_period) : c;
+  const float sc = e.scale ? e.scale[si] : 1.f;
   if (e.mode == TG_EPI_FWD) {
-    const float sh = e.shift ? e.shift[c] : 0.f;
+    const float sh = e.shift ? e.shift[si] : 0.f;
     return apply_act(acc * sc + sh, e.act);
   }
   const float yf = e.yfwd ? e.yfwd[yoff] : 0.f;

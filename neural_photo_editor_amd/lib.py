@@ -41,7 +41,7 @@ class ModelDesc(C.Structure):
 
 EXPORTS = (
     "ian_create", "ian_load_param", "ian_set_made_masks", "ian_finalize", "ian_encode", "ian_decode",
-    "ian_encode_pre_iaf", "ian_iaf", "ian_reconstruct", "ian_grad_rgb", "ian_grad_light", "ian_read_slot",
+    "ian_encode_pre_iaf", "ian_iaf", "ian_reconstruct", "ian_grad_rgb", "ian_grad_light", "ian_read_slot", "ian_read_slot_grad",
     "ian_profile_enable", "ian_profile_read", "ian_set_option", "ian_last_error", "ian_version", "ian_destroy",
 )
 
@@ -74,6 +74,7 @@ def load_library():
     lib.ian_grad_rgb.argtypes = [vp, i32, i32, i32, i32, fp, fp, fp, vp]
     lib.ian_grad_light.argtypes = [vp, i32, i32, i32, i32, fp, fp, vp]
     lib.ian_read_slot.argtypes = [vp, i32, i32, fp, vp]
+    lib.ian_read_slot_grad.argtypes = [vp, i32, i32, fp, vp]
     lib.ian_profile_enable.argtypes = [vp, i32]
     lib.ian_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
@@ -172,6 +173,12 @@ class Handle:
         h, w, c = self.lowered.slots[slot]
         out = np.empty((n, c, h, w), np.float32)
         self._check(self.lib.ian_read_slot(self._h, slot, n, _ptr(out), C.c_void_p(0)))
+        return out
+
+    def read_slot_grad(self, slot, n=1):
+        h, w, c = self.lowered.slots[slot]
+        out = np.empty((n, c, h, w), np.float32)
+        self._check(self.lib.ian_read_slot_grad(self._h, slot, n, _ptr(out), C.c_void_p(0)))
         return out
 
     def profile_enable(self, on=True):

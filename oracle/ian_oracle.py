@@ -427,10 +427,10 @@ def make_params(arch, seed=1):
         P[name] = np.asarray(v, np.float32)
     # keep deep random nets in a sane numeric range
     if arch == "IAN_simple":
-        P["dec_out.W"] *= 0.15
+        P["dec_out.W"] *= 1.0
     else:
         for nm in ("R", "G_a", "B_a"):
-            P[nm + "W"] *= 0.5
+            P[nm + "W"] *= 4.0
         for nm in ("G_b", "B_b"):
             P[nm + "W"] *= 25.0
         for blk in ("dec_conv2a", "dec_conv3a", "dec_conv4a"):

@@ -1,0 +1,210 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the ctypes host class) against the CPU oracle
+and the committed golden vectors.  Tolerance for float32 activations is the north star's 1e-4 relative
+(max-abs-error / max-abs-reference); MADE masks are checked bit-exactly in test_host.py."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ian_oracle as O
+from oracle.torch_twin import TorchTwin
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "neural_photo_editor_amd", "configs")
+GOLD = os.path.join(ROOT, "tests", "golden")
+TOL = 1e-4        # north-star tolerance on float32 activations
+TOL_GRAD = 5e-4   # gradients: fp32 chain of 5 transposed maps vs a float64 reference
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-30))
+
+
+def red_rgb():
+    rgb = np.full((1, 3, 64, 64), -1.0, np.float32)
+    rgb[:, 0] = 1.0
+    return rgb
+
+
+_cache = {}
+
+
+def model_for(arch):
+    if arch not in _cache:
+        from neural_photo_editor_amd import IAN
+        P = O.make_params(arch, 1)
+        _cache[arch] = (IAN(os.path.join(CFG, arch + ".py"), True, params=P), O.Oracle(arch, P), P)
+    return _cache[arch]
+
+
+def test_native_library_is_loaded():
+    """The product path is libian.so; make the loaded-library evidence explicit."""
+    model_for("IAN_simple")
+    maps = open("/proc/self/maps").read()
+    assert "libian.so" in maps
+
+
+@pytest.mark.parametrize("arch", O.ARCHS)
+def test_golden_encode_decode(arch):
+    m, orc, _ = model_for(arch)
+    g = np.load(os.path.join(GOLD, "%s_seed1.npz" % arch))
+    x = O.make_images(2)
+    assert rel(m.Zfn(x), g["zpre"]) < TOL
+    assert rel(m.encode_images(x), g["z"]) < TOL
+    assert rel(m.sample_at(g["z"]), g["xhat"]) < TOL
+    assert rel(m.sample_at(g["z_sample"]), g["x_sample"]) < TOL
+    assert rel(m.reconstruct(x), g["xhat"]) < TOL
+    assert rel(m.Z_IAF_fn(g["zpre"]), g["z"]) < TOL
+    assert rel(m.sample(g["zpre"]), g["xhat"]) < TOL
+    assert m.get_zdim() == 100
+
+
+@pytest.mark.parametrize("arch", O.ARCHS)
+@pytest.mark.parametrize("n", [1, 3, 5, 33])
+def test_ragged_batches_vs_oracle(arch, n):
+    m, orc, _ = model_for(arch)
+    x = O.make_images(n, seed=10 + n)
+    z = m.encode_images(x)
+    zr = orc.encode_images(x)
+    assert z.shape == (n, 100) and rel(z, zr) < TOL
+    xh = m.sample_at(zr)
+    assert xh.shape == (n, 3, 64, 64) and rel(xh, orc.sample_at(zr)) < TOL
+
+
+@pytest.mark.parametrize("arch", O.ARCHS)
+def test_every_layer_activation(arch):
+    m, orc, _ = model_for(arch)
+    n = 3
+    x = O.make_images(n, seed=5)
+    z = m.encode_images(x)
+    for i, f in enumerate(orc.encoder_features(x)):
+        assert rel(m.activation("enc_conv%d" % (i + 1), n), f) < TOL, "enc_conv%d" % (i + 1)
+    zr = orc.encode_images(x)
+    m.sample_at(zr)
+    # the fused op that ends an MDBLOCK / a colour head is named after its last MDCL
+    rename = {"dec_fc2": "l_dec_fc2", "out": "l_out", "dec_conv2a": "dec_conv2a2", "dec_conv3a": "dec_conv3a2",
+              "dec_conv4a": "dec_conv4a2", "G": "G_b", "B": "B_b"}
+    checked = 0
+    for name, a in orc.decoder_activations(zr):
+        nm = rename.get(name, name)
+        if nm in m.lowered.slot_names:
+            assert rel(m.activation(nm, n), a) < TOL, name
+            checked += 1
+    assert checked == (5 if arch == "IAN_simple" else 12)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+def test_every_tile_config_and_split_policy(cfg):
+    """All tapgemm tile shapes, with and without split-K, give the same answer."""
+    m, orc, _ = model_for("IAN_simple")
+    x = O.make_images(3, seed=7)
+    ref = orc.reconstruct(x)
+    try:
+        for split in (1, 0):
+            m.handle.set_option("tg_cfg", cfg)
+            m.handle.set_option("tg_split", split)
+            assert rel(m.reconstruct(x), ref) < TOL
+        m.handle.set_option("tg_target_items", 4096)   # aggressive split-K
+        m.handle.set_option("tg_min_steps", 1)
+        m.handle.set_option("tg_split", 1)
+        assert rel(m.reconstruct(x), ref) < TOL
+    finally:
+        for k, v in (("tg_cfg", -1), ("tg_split", 1), ("tg_target_items", 768), ("tg_min_steps", 16)):
+            m.handle.set_option(k, v)
+
+
+def test_brush_gradients_vs_golden():
+    m, _, P = model_for("IAN_simple")
+    g = np.load(os.path.join(GOLD, "IAN_simple_seed1.npz"))
+    z = g["z_sample"][:1]
+    got = m.imgradRGB(26, 26, 30, 30, red_rgb(), z)
+    assert got.shape == (1, 100) and rel(got, g["grad_rgb"]) < TOL_GRAD
+    assert rel(m.imgrad(26, 26, 30, 30, z), g["grad_light"]) < TOL_GRAD
+    # float-valued ints from Tk (NPE.py:202) are accepted
+    assert np.array_equal(m.imgrad(26.0, 26.0, 30.0, 30.0, z), m.imgrad(26, 26, 30, 30, z))
+
+
+@pytest.mark.parametrize("patch", [(0, 0, 64, 64), (0, 0, 1, 1), (63, 63, 64, 64), (10, 20, 30, 40), (60, 0, 64, 9)])
+def test_brush_gradients_patches_vs_twin(patch):
+    m, _, P = model_for("IAN_simple")
+    import torch
+    tw = TorchTwin("IAN_simple", P, dtype=torch.float64)
+    z = O.make_latents(1, seed=11)
+    rgb = np.random.RandomState(4).uniform(-1, 1, (1, 3, 64, 64)).astype(np.float32)
+    c1, r1, c2, r2 = patch
+    assert rel(m.imgradRGB(c1, r1, c2, r2, rgb, z), tw.imgradRGB(c1, r1, c2, r2, rgb, z)) < TOL_GRAD
+    assert rel(m.imgrad(c1, r1, c2, r2, z), tw.imgrad(c1, r1, c2, r2, z)) < TOL_GRAD
+
+
+def test_edit_loop_trajectory():
+    """NPE.paint's update (NPE.py:199-209): Z -= 0.05 * grad * (1 + (x2 - x1)), 10 steps, vs the twin."""
+    m, _, P = model_for("IAN_simple")
+    tw = TorchTwin("IAN_simple", P)
+    z_gpu = O.make_latents(1, seed=2).copy()
+    z_ref = z_gpu.copy()
+    c1, r1, c2, r2 = 26, 26, 30, 30
+    rgb = red_rgb()
+    for _ in range(10):
+        z_gpu = z_gpu - 0.05 * m.imgradRGB(c1, r1, c2, r2, rgb, z_gpu) * (1 + (c2 - c1))
+        z_ref = z_ref - 0.05 * tw.imgradRGB(c1, r1, c2, r2, rgb, z_ref) * (1 + (c2 - c1))
+    assert rel(z_gpu, z_ref) < TOL
+    assert rel(m.sample_at(z_gpu), tw.np_decode(z_ref)) < TOL
+
+
+def test_device_pointers_equal_host_pointers():
+    import torch
+    m, _, _ = model_for("IAN_simple")
+    x = O.make_images(4, seed=3)
+    host = m.reconstruct(x)
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty_like(xd)
+    m.handle.call("ian_reconstruct", xd, 4, out, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), host)
+    zd = torch.empty((4, 100), device="cuda")
+    m.handle.call("ian_encode", xd, 4, zd)
+    torch.cuda.synchronize()
+    assert np.array_equal(zd.cpu().numpy(), m.encode_images(x))
+
+
+# ---- full-size (BASELINE.json configs 2 and 3) size-independent properties --------------------------------
+@pytest.mark.parametrize("arch,B", [("IAN_simple", 64), ("IAN", 256)])
+def test_full_size_properties(arch, B):
+    m, orc, _ = model_for(arch)
+    x = O.make_images(B, seed=21)
+    xh = m.reconstruct(x)
+    assert xh.shape == (B, 3, 64, 64) and np.isfinite(xh).all() and np.abs(xh).max() <= 1.0
+    # (a) images are independent: permuting the batch permutes the output, bit for bit
+    perm = np.random.RandomState(0).permutation(B)
+    assert np.array_equal(m.reconstruct(x[perm]), xh[perm])
+    # (b) a sample of the batch against the oracle
+    idx = [0, B // 2, B - 1]
+    assert rel(xh[idx], orc.reconstruct(x[idx])) < TOL
+    # (c) encode followed by decode equals reconstruct
+    assert rel(m.sample_at(m.encode_images(x)), xh) < 1e-6
+
+
+# ---- error behaviour ------------------------------------------------------------------------------------------
+def test_errors_surface_as_exceptions():
+    from neural_photo_editor_amd.lib import IanError
+    m, _, _ = model_for("IAN_simple")
+    with pytest.raises(ValueError):
+        m.encode_images(np.zeros((0, 3, 64, 64), np.float32))
+    with pytest.raises(ValueError):
+        m.encode_images(np.zeros((2, 3, 32, 32), np.float32))
+    with pytest.raises(ValueError):
+        m.sample_at(np.zeros((2, 99), np.float32))
+    with pytest.raises(IanError):
+        m.imgrad(0, 0, 65, 64, np.zeros((1, 100), np.float32))
+    # empty patch: mean over nothing; the reference would give NaN, we return a zero gradient without crashing
+    g = m.imgrad(5, 5, 5, 5, np.zeros((1, 100), np.float32))
+    assert np.all(g == 0)
+
+
+def test_imgrad_on_full_ian_fails_loudly_until_implemented():
+    from neural_photo_editor_amd.lib import IanError
+    m, _, _ = model_for("IAN")
+    with pytest.raises(IanError, match="backward"):
+        m.imgrad(26, 26, 30, 30, np.zeros((1, 100), np.float32))

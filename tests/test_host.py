@@ -1,0 +1,169 @@
+"""CPU tests of the host side: config recorder, lowering, MADE masks (product code), checkpoint format,
+and that the C-ABI library builds, loads and exports every symbol include/ian.h declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from neural_photo_editor_amd import checkpoints, config_loader as cl, lowering, made
+from neural_photo_editor_amd import lib as L
+from oracle import ian_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "neural_photo_editor_amd", "configs")
+REF = "/root/reference"
+
+
+def lowered(path, dnn=True):
+    mod = cl.load_config(path)
+    return mod, lowering.lower_model(cl.build_model(mod, dnn=dnn))
+
+
+def op_signature(low):
+    return [(o.kind, o.segment, o.src, o.src2, o.src3, o.dst, o.cin, o.cout, o.in_h, o.in_w, o.act, o.has_bias,
+             tuple(o.flat), tuple(o.unflat), tuple(o.scales), o.name, o.bn_name) for o in low.ops]
+
+
+def test_ian_simple_lowering():
+    mod, low = lowered(os.path.join(CFG, "IAN_simple.py"))
+    assert mod.cfg["num_latents"] == 100 and low.num_latents == 100
+    kinds = [o.kind for o in low.ops]
+    assert kinds == [1, 1, 1, 1, 4, 4, 4, 2, 2, 2, 2]
+    assert low.zpre_slot == low.z_slot and not low.has_made
+    names = [o.name for o in low.ops]
+    assert names == ["enc_conv1", "enc_conv2", "enc_conv3", "enc_conv4", "enc_fc1", "enc_mu", "l_dec_fc2",
+                     "dec_conv1", "dec_conv2", "dec_conv3", "dec_out"]
+    fc1, fc2 = low.ops[4], low.ops[6]
+    assert fc1.flat == (1024, 4, 4) and fc1.act == lowering.ACTS["elu"] and fc1.bn_name == "bnorm_enc_fc1"
+    assert fc2.unflat == (1024, 4, 4) and fc2.act == lowering.ACTS["relu"] and fc2.has_bias == 0
+    assert low.ops[0].has_bias == 1 and low.ops[1].has_bias == 0   # batch_norm strips the bias (App. B.3)
+    assert low.ops[-1].act == lowering.ACTS["tanh"] and low.ops[-1].bn_name is None
+    assert low.slots[low.out_slot] == (64, 64, 3)
+    # parameter inventory == the oracle's inference parameter set minus the unused log-sigma head
+    want = set(O.param_shapes("IAN_simple")) - {"enc_logsigma.W"} - {"ls_bnorm." + s for s in ("beta", "gamma", "mean", "inv_std")}
+    assert {p.name for p in low.params} == want
+    shapes = O.param_shapes("IAN_simple")
+    assert all(tuple(shapes[p.name]) == p.shape for p in low.params)
+
+
+def test_ian_simple_dnn_false_branch_is_the_same_graph():
+    """TransposedConv2DLayer(crop=1)+SliceLayer (IAN_simple.py:182-223) lowers to the same ops."""
+    _, a = lowered(os.path.join(CFG, "IAN_simple.py"), dnn=True)
+    _, b = lowered(os.path.join(CFG, "IAN_simple.py"), dnn=False)
+    assert op_signature(a) == op_signature(b)
+
+
+def test_ian_lowering():
+    mod, low = lowered(os.path.join(CFG, "IAN.py"))
+    assert low.has_made and low.zpre_slot != low.z_slot
+    by_name = {o.name: o for o in low.ops}
+    assert by_name["l_IAF"].kind == lowering.OP_MADE_IAF and by_name["l_IAF"].segment == lowering.SEG_IAF
+    # MDBLOCK (layers.py:411-416): affine(bnorm0) -> mdc(bnorm1) -> mdc + residual(bnorm2)
+    blk = [o for o in low.ops if o.name.startswith("dec_conv2a")]
+    assert [o.kind for o in blk] == [lowering.OP_AFFINE, lowering.OP_MDC3, lowering.OP_MDC3]
+    assert blk[0].bn_name == "dec_conv2abnorm0" and blk[0].act == lowering.ACTS["lrelu"]
+    assert blk[1].bn_name == "dec_conv2abnorm1" and blk[1].src == blk[0].dst and blk[1].scales == [0, 2]
+    assert blk[2].bn_name == "dec_conv2abnorm2" and blk[2].src2 == by_name["dec_conv1"].dst
+    # the deconv under an MDBLOCK loses its bias to batch_norm() (App. B.3)
+    assert by_name["dec_conv1"].has_bias == 0 and by_name["dec_conv1"].act == 0
+    assert by_name["l_dec_fc2"].has_bias == 1 and by_name["l_dec_fc2"].unflat == (512, 4, 4)
+    # RGB-Beta head (IAN.py:183-207)
+    assert by_name["G_b"].src == by_name["R"].dst and by_name["G_b"].src2 == by_name["G_a"].dst
+    assert by_name["B_b"].cin == 4 and by_name["B_b"].act == lowering.ACTS["sigmoid"]
+    assert low.ops[-1].kind == lowering.OP_BETA
+    assert {p.name for p in low.params} | {"enc_logsigma.W"} | {"ls_bnorm." + s for s in ("beta", "gamma", "mean", "inv_std")} \
+        == set(O.param_shapes("IAN"))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present (GPU box)")
+@pytest.mark.parametrize("name,dnn", [("IAN_simple.py", True), ("IAN_simple.py", False), ("IAN.py", True)])
+def test_reference_configs_load_unchanged(name, dnn):
+    """The reference's own config files execute under the recorder and give the graph of our configs."""
+    _, ours = lowered(os.path.join(CFG, name), dnn=dnn)
+    mod, theirs = lowered(os.path.join(REF, name), dnn=dnn)
+    assert op_signature(ours) == op_signature(theirs)
+    assert [(p.name, p.shape) for p in ours.params] == [(p.name, p.shape) for p in theirs.params]
+    assert ours.slots == theirs.slots
+    ours_mod = cl.load_config(os.path.join(CFG, name))
+    assert ours_mod.cfg == mod.cfg
+
+
+def test_stub_environment_is_removed_afterwards():
+    import sys
+    cl.load_config(os.path.join(CFG, "IAN_simple.py"))
+    assert "lasagne" not in sys.modules and "theano" not in sys.modules and "layers" not in sys.modules
+
+
+def test_unsupported_graph_fails_loudly():
+    mod = cl.load_config(os.path.join(CFG, "IAN_simple.py"))
+    with cl.stub_environment():
+        model = mod.get_model(dnn=True)
+        import lasagne
+        model["l_out"] = lasagne.layers.Conv2DLayer(model["l_out"], 3, 3, pad=1, name="extra")
+    with pytest.raises(lowering.LoweringError):
+        lowering.lower_model(model)
+
+
+# ---- MADE masks in the product path ------------------------------------------------------------------------
+def test_product_made_masks_bit_exact():
+    got = made.masks_once(100)
+    want = O.made_masks()
+    for a, b in zip(got, want):
+        assert a.dtype == np.float32 and np.array_equal(a, b)
+    assert [int(m.sum()) for m in got] == [100, 9900, 4950]
+    assert made.shuffled_ordering(100)[:6].tolist() == [52, 79, 87, 45, 24, 71]
+
+
+# ---- checkpoint format (GANcheckpoints.py:11-57) ---------------------------------------------------------
+def test_checkpoint_roundtrip_and_mismatch_policy(tmp_path):
+    _, low = lowered(os.path.join(CFG, "IAN_simple.py"))
+    specs = [p for p in low.params if p.name in ("enc_conv1.W", "enc_conv1.b", "bnorm2.mean")]
+    rs = np.random.RandomState(0)
+    arrays = {p.name: rs.randn(*p.shape).astype(np.float32) for p in specs}
+    arrays["bnorm2.mean"] = np.zeros((7,), np.float32)  # wrong shape -> skipped with a warning
+    f = tmp_path / "w.npz"
+    checkpoints.save_weights(f, arrays, metadata={"epoch": 3, "learning_rate": 2e-4})
+    checkpoints.save_weights(f, arrays, metadata={"epoch": 4, "learning_rate": 1e-4})  # overwrite via tmp + rename
+    with pytest.warns(UserWarning):
+        got, meta = checkpoints.load_weights(f, specs)
+    assert meta == {"epoch": 4, "learning_rate": 1e-4}
+    assert set(got) == {"enc_conv1.W", "enc_conv1.b"}
+    assert np.array_equal(got["enc_conv1.W"], arrays["enc_conv1.W"])
+
+
+# ---- C ABI ---------------------------------------------------------------------------------------------------
+def test_library_builds_loads_and_exports_header_symbols():
+    lib = L.load_library()
+    header = open(os.path.join(ROOT, "include", "ian.h")).read()
+    declared = set(re.findall(r"\b(ian_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(L.EXPORTS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    assert b"gfx950" in lib.ian_version()
+
+
+def test_struct_layout_matches_header():
+    # ian_op_desc: 18 int32 + n_scales + 4 scales = 23 int32 (92 B) padded to 96, then two pointers
+    assert ctypes.sizeof(L.OpDesc) == 96 + 16
+    assert L.OpDesc.name.offset == 96
+    assert ctypes.sizeof(L.SlotDesc) == 12
+
+
+def test_model_creation_without_gpu_fails_loudly_not_silently():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from neural_photo_editor_amd import IAN
+    with pytest.raises(L.IanError, match="no HIP device"):
+        IAN(os.path.join(CFG, "IAN_simple.py"), True, params=O.make_params("IAN_simple", 1))
+
+
+def test_missing_parameter_is_an_error_in_the_c_layer():
+    _, low = lowered(os.path.join(CFG, "IAN_simple.py"))
+    h = L.Handle(low)
+    h.load_param("enc_conv1.W", np.zeros((128, 3, 5, 5), np.float32))
+    with pytest.raises(L.IanError):
+        h.finalize()   # either "no HIP device" (CPU box) or "missing parameter" (GPU box): never a silent success
+    h.close()
