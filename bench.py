@@ -89,6 +89,9 @@ def main():
     P = O.make_params(arch, seed=1)
     model = IAN(os.path.join(ROOT, "neural_photo_editor_amd", "configs", arch + ".py"), True, params=P)
     h = model.handle
+    for kv in filter(None, os.environ.get("IAN_OPTS", "").split(",")):  # tuning knobs, e.g. IAN_OPTS=tg_cfg=0
+        k, v = kv.split("=")
+        h.set_option(k, int(v))
     x = torch.from_numpy(O.make_images(B, seed=100 + rank)).cuda()
     out = torch.empty_like(x)
     stream = torch.cuda.current_stream().cuda_stream
@@ -102,6 +105,9 @@ def main():
     def step():
         h.call("ian_reconstruct", x, B, out, stream=stream)
 
+    step()
+    if not os.environ.get("IAN_NO_AUTOTUNE"):
+        h.autotune(B, 1, stream=stream)  # untimed: pick tile shape / split-K per layer for this batch on this GPU
     for _ in range(args.warmup):
         step()
     barrier()
@@ -139,6 +145,9 @@ def main():
             z = O.make_latents(1, seed=2)
             rgb = np.full((1, 3, 64, 64), -1.0, np.float32); rgb[:, 0] = 1.0
             c1, r1, c2, r2 = 26, 26, 30, 30
+            model.imgradRGB(c1, r1, c2, r2, rgb, z)
+            if not os.environ.get("IAN_NO_AUTOTUNE"):
+                h.autotune(1, 3)
             lat = []
             for i in range(120):
                 t = time.perf_counter()

@@ -142,6 +142,11 @@ int ian_read_slot_grad(ian_handle* h, int32_t slot, int32_t n, float* out, void*
 int ian_profile_enable(ian_handle* h, int32_t on);
 int ian_profile_read(ian_handle* h, double* tapgemm_ms, int64_t* tapgemm_launches, double* tapgemm_flops,
                      double* total_ms);
+/* Time candidate (tile shape, split-K) decompositions of every tapgemm layer for batch n on this device and keep
+   the fastest.  what: bit 0 = forward ops (needs one prior forward call with batch >= n), bit 1 = latent-brush
+   backward chain (n must be 1, needs one prior ian_grad_* call).  Results are identical for every choice up to
+   float32 summation order; without this call a static heuristic is used. */
+int ian_autotune(ian_handle* h, int32_t n, int32_t what, void* stream);
 /* Tuning knobs (tile shape / split-K policy); key=value, returns <0 on unknown key. */
 int ian_set_option(ian_handle* h, const char* key, int32_t value);
 

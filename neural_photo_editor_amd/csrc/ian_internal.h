@@ -60,6 +60,7 @@ struct TgParams {
   int so;                    // output coordinate = q*so + p
   int OH, OW, Cout, y_stride;
   int CoutPad;
+  unsigned x_bytes, w_bytes;  // buffer-descriptor extents (out-of-range offsets read as zero)
 };
 
 struct TgReduceParams {

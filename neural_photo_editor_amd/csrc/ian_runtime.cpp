@@ -47,6 +47,11 @@ struct Schedule {
   std::vector<TgTile> h_tiles;
 };
 
+struct TgChoice {  // autotuned (or forced) schedule shape for one (layer, batch)
+  int cfg = -1;        // enum TgConfig, -1 = heuristic
+  int max_steps = -1;  // -1 = heuristic, 0 = never split K, >0 = split so that no item exceeds this many K-steps
+};
+
 // one linear map executed by the tapgemm kernel (forward or backward-data form of an op)
 struct TgLayer {
   bool valid = false;
@@ -54,11 +59,13 @@ struct TgLayer {
   int cin_real = 0;  // for FLOP accounting
   std::vector<TgClass> classes;
   std::vector<TgTap> taps;
-  std::vector<float> h_w;  // packed weights (freed after upload unless keep_host)
+  std::vector<float> h_w;  // packed weights (freed after upload)
+  size_t w_floats = 0;
   float* d_w = nullptr;
   TgClass* d_classes = nullptr;
   TgTap* d_taps = nullptr;
   std::map<int, Schedule> sched;  // per batch size
+  std::map<int, TgChoice> choice;  // per batch size, set by ian_autotune
   double macs_per_image() const {
     double m = 0;
     for (auto& c : classes) m += (double)QH * QW * c.ntaps * cin_real * Cout;
@@ -96,6 +103,8 @@ struct Options {
   int tg_no_split_items = 384;  // do not split when tiles alone give at least this many workgroups
   int tg_split = 1;
   int tg_xcd_group = 8;       // supergroup edge (tiles) dealt to one XCD
+  int tg_prefer_nosplit = 1;  // try smaller tiles before resorting to split-K
+  int tg_nosplit_min_out = 1 << 30;  // outputs (M*Cout) above which 64x64 is forced even if it under-fills
 };
 
 }  // namespace
@@ -472,6 +481,8 @@ int upload_layer(ian_handle* h, TgLayer& L) {
   if (!L.valid) return 0;
   if (ilog2_exact(L.QW) < 0 || ilog2_exact(L.QH * L.QW) < 0) return fail(h, -4, "tapgemm needs power-of-two output grids");
   int rc;
+  L.w_floats = L.h_w.size();
+  if (L.w_floats * 4 > 0xFFFFFFF0ull) return fail(h, -4, "packed weights exceed the 4 GiB buffer-descriptor range");
   if ((rc = upload(h, L.h_w, &L.d_w))) return rc;
   if ((rc = upload(h, L.classes, &L.d_classes))) return rc;
   if ((rc = upload(h, L.taps, &L.d_taps))) return rc;
@@ -480,6 +491,11 @@ int upload_layer(ian_handle* h, TgLayer& L) {
 }
 
 // ----- scheduling: tiles, split-K, heavy-first + XCD-aware item order ---------------------------------
+static int count_tiles(const TgLayer& L, int M, int cfg) {
+  const TgShape sh = tg_shape(cfg);
+  return ((M + sh.bm - 1) / sh.bm) * ((L.Cout + sh.bn - 1) / sh.bn) * (int)L.classes.size();
+}
+
 int pick_config(const ian_handle* h, const TgLayer& L, int M) {
   if (h->opt.tg_cfg >= 0 && h->opt.tg_cfg < TG_NCONFIG) {
     const TgShape s = tg_shape(h->opt.tg_cfg);
@@ -488,12 +504,20 @@ int pick_config(const ian_handle* h, const TgLayer& L, int M) {
   if (L.Cout <= 32) return TG_128x32;
   if (M <= 32) return TG_32x128;
   if (M <= 64) return TG_64x64;
+  // Large output maps: a smaller tile that fills the chip WITHOUT split-K beats 128x128 + slabs (the slab
+  // write + reduce pass moves the whole output several times).  Small-M / huge-K layers keep 128x128 + split-K.
+  if (h->opt.tg_prefer_nosplit) {
+    const int order[3] = {TG_128x128, TG_128x64, TG_64x64};
+    for (int c : order)
+      if (count_tiles(L, M, c) >= h->opt.tg_no_split_items) return c;
+    if ((long long)M * L.Cout >= (long long)h->opt.tg_nosplit_min_out) return TG_64x64;
+  }
   return TG_128x128;
 }
 
-void build_schedule(const ian_handle* h, const TgLayer& L, int nimg, Schedule& S) {
+void build_schedule(const ian_handle* h, const TgLayer& L, int nimg, Schedule& S, const TgChoice& ch) {
   const int M = nimg * L.QH * L.QW;
-  S.cfg = pick_config(h, L, M);
+  S.cfg = (ch.cfg >= 0 && ch.cfg < TG_NCONFIG && L.CoutPad % tg_shape(ch.cfg).bn == 0) ? ch.cfg : pick_config(h, L, M);
   const TgShape sh = tg_shape(S.cfg);
   const int tiles_m = (M + sh.bm - 1) / sh.bm;
   const int tiles_n = (L.Cout + sh.bn - 1) / sh.bn;
@@ -507,12 +531,14 @@ void build_schedule(const ian_handle* h, const TgLayer& L, int nimg, Schedule& S
   }
   int steps_per_item = 1 << 30;
   bool split = false;
-  if (h->opt.tg_split && total_tiles < h->opt.tg_no_split_items) {
+  if (ch.max_steps > 0) {
+    steps_per_item = ch.max_steps;
+  } else if (ch.max_steps < 0 && h->opt.tg_split && total_tiles < h->opt.tg_no_split_items) {
     long long spi = (total_steps + h->opt.tg_target_items - 1) / h->opt.tg_target_items;
     steps_per_item = (int)std::max<long long>(spi, h->opt.tg_min_steps);
-    for (auto& c : L.classes)
-      if (c.ntaps * kpt > steps_per_item) split = true;
   }
+  for (auto& c : L.classes)
+    if (c.ntaps * kpt > steps_per_item) split = true;
   struct Group {
     std::vector<TgItem> items;
     int weight;
@@ -582,7 +608,8 @@ int get_schedule(ian_handle* h, TgLayer& L, int nimg, Schedule** out) {
   auto it = L.sched.find(nimg);
   if (it == L.sched.end()) {
     Schedule S;
-    build_schedule(h, L, nimg, S);
+    auto chit = L.choice.find(nimg);
+    build_schedule(h, L, nimg, S, chit == L.choice.end() ? TgChoice() : chit->second);
     int rc;
     if ((rc = upload(h, S.h_items, &S.d_items))) return rc;
     if ((rc = upload(h, S.h_tiles, &S.d_tiles))) return rc;
@@ -597,6 +624,14 @@ int get_schedule(ian_handle* h, TgLayer& L, int nimg, Schedule** out) {
   }
   *out = &it->second;
   return 0;
+}
+
+void free_schedule_for(TgLayer& L, int nimg) {
+  auto it = L.sched.find(nimg);
+  if (it == L.sched.end()) return;
+  if (it->second.d_items) (void)hipFree(it->second.d_items);
+  if (it->second.d_tiles) (void)hipFree(it->second.d_tiles);
+  L.sched.erase(it);
 }
 
 void free_schedules(TgLayer& L) {
@@ -645,6 +680,10 @@ int run_tapgemm(ian_handle* h, TgLayer& L, int nimg, const float* x, float* y, i
   p.qw_shift = ilog2_exact(L.QW); p.qhw_shift = ilog2_exact(L.QH * L.QW);
   p.si = L.si; p.by = L.by; p.bx = L.bx; p.so = L.so;
   p.OH = L.OH; p.OW = L.OW; p.Cout = L.Cout; p.y_stride = y_stride; p.CoutPad = L.CoutPad;
+  const size_t xb = (size_t)nimg * L.IH * L.IW * L.Cin * sizeof(float);
+  if (xb > 0xFFFFFFF0ull) return fail(h, -7, "batch %d makes a %zu-byte activation: above the 4 GiB buffer-descriptor range, split the batch", nimg, xb);
+  p.x_bytes = (unsigned)xb;
+  p.w_bytes = (unsigned)(L.w_floats * sizeof(float));
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (h->prof) {
     if (h->ev_used == h->ev_pool.size()) {
@@ -731,6 +770,89 @@ int run_segment(ian_handle* h, int seg, int n, hipStream_t st) {
       int rc = run_op_fwd(h, op, n, st);
       if (rc) return rc;
     }
+  return 0;
+}
+
+// ----- autotuner: per (layer, batch) pick tile shape x split-K policy by timing the real launch ------------
+// The 9/6/6/4-tap parity classes, the 4^2..64^2 spatial extents and batch sizes from 1 to 1024 make the best
+// (tile, K-range) decomposition layer specific; candidates are timed with HIP events on the caller's stream.
+struct TuneCand {
+  TgChoice ch;
+  float ms;
+};
+
+std::vector<TgChoice> tune_candidates(const TgLayer& L, int nimg) {
+  const int M = nimg * L.QH * L.QW;
+  std::vector<int> cfgs;
+  if (L.Cout <= 32) cfgs = {TG_128x32};
+  else if (M <= 32) cfgs = {TG_32x128, TG_64x64};
+  else if (M <= 64) cfgs = {TG_64x64, TG_32x128, TG_128x64};
+  else {
+    cfgs = {TG_128x128, TG_128x64, TG_64x64};
+    if (M >= 512 && L.Cout >= 128) cfgs.push_back(TG_256x128);
+  }
+  int max_ksteps = 0;
+  for (auto& c : L.classes) max_ksteps = std::max(max_ksteps, c.ntaps * (L.Cin / 32));
+  std::vector<TgChoice> out;
+  for (int cfg : cfgs) {
+    const TgShape sh = tg_shape(cfg);
+    const long long tiles = (long long)((M + sh.bm - 1) / sh.bm) * ((L.Cout + sh.bn - 1) / sh.bn);
+    for (int ms : {0, 8, 16, 32, 64, 128, 256}) {
+      if (ms > 0 && ms >= max_ksteps) continue;  // would not split anything
+      if (ms > 0) {
+        long long slabs = 0;
+        for (auto& c : L.classes) slabs += tiles * ((c.ntaps * (L.Cin / 32) + ms - 1) / ms);
+        if (slabs * sh.bm * sh.bn * 4 > (512ll << 20)) continue;  // slab workspace cap
+        if (slabs > 16384) continue;
+      }
+      TgChoice c;
+      c.cfg = cfg;
+      c.max_steps = ms;
+      out.push_back(c);
+    }
+  }
+  return out;
+}
+
+template <typename F>
+int time_launches(ian_handle* h, hipStream_t st, int reps, F&& fn, float* ms) {
+  hipEvent_t a, b;
+  HIPCHK(h, hipEventCreate(&a));
+  HIPCHK(h, hipEventCreate(&b));
+  int rc = fn();  // warm-up (also builds + uploads the schedule)
+  if (!rc) {
+    (void)hipEventRecord(a, st);
+    for (int r = 0; r < reps && !rc; ++r) rc = fn();
+    (void)hipEventRecord(b, st);
+    (void)hipEventSynchronize(b);
+    float t = 0;
+    (void)hipEventElapsedTime(&t, a, b);
+    *ms = t / reps;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return rc;
+}
+
+template <typename F>
+int tune_layer(ian_handle* h, TgLayer& L, int nimg, hipStream_t st, F&& run, TgChoice* best_out, float* best_ms) {
+  TgChoice best;
+  float bms = 1e30f;
+  for (const TgChoice& c : tune_candidates(L, nimg)) {
+    L.choice[nimg] = c;
+    free_schedule_for(L, nimg);
+    float ms = 0;
+    int rc = time_launches(h, st, 3, run, &ms);
+    if (rc) return rc;
+    if (ms < bms) {
+      bms = ms;
+      best = c;
+    }
+  }
+  L.choice[nimg] = best;
+  free_schedule_for(L, nimg);
+  if (best_out) *best_out = best;
+  if (best_ms) *best_ms = bms;
   return 0;
 }
 
@@ -1078,6 +1200,62 @@ int ian_reconstruct(ian_handle* h, const float* x, int32_t n, float* xhat, void*
   return get_image_output(h, xhat, n, st);
 }
 
+int ian_autotune(ian_handle* h, int32_t n, int32_t what, void* stream) {
+  int rc = check_ready(h, n);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const bool prof = h->prof;
+  h->prof = false;
+  const bool verbose = getenv("IAN_DEBUG") != nullptr;
+  static const char* cfg_names[TG_NCONFIG] = {"128x128", "128x64", "64x64", "32x128", "256x128", "128x32"};
+  auto have = [&](int slot, bool grad) {
+    if (slot < 0) return true;
+    const Slot& s = h->slots[slot];
+    return (grad ? s.gcap : s.cap) >= s.per_image() * (size_t)n && (grad ? s.g : s.d) != nullptr;
+  };
+  if (what & 1) {
+    for (auto& op : h->ops) {
+      if (!op.fwd.valid) continue;
+      if (!have(op.d.src, false) || !have(op.d.src2, false) || !have(op.d.dst, false)) {
+        h->prof = prof;
+        return fail(h, -6, "ian_autotune: run a forward call with batch >= %d first (op '%s' has no activations)", n, op.name.c_str());
+      }
+      TgChoice best;
+      float ms = 0;
+      OpPlan* opp = &op;
+      if ((rc = tune_layer(h, op.fwd, n, st, [&]() { return run_op_fwd(h, *opp, n, st); }, &best, &ms))) break;
+      if (verbose)
+        fprintf(stderr, "[ian_autotune] n=%d fwd %-14s -> tile %s, max K-steps/item %d : %.1f us (%.1f TF/s)\n", n,
+                op.name.c_str(), cfg_names[best.cfg], best.max_steps, ms * 1e3,
+                2.0 * op.fwd.macs_per_image() * n / (ms * 1e-3) / 1e12);
+    }
+  }
+  if (!rc && (what & 2)) {
+    if (n != 1) {
+      h->prof = prof;
+      return fail(h, -7, "ian_autotune: the latent-brush backward is a batch-1 path");
+    }
+    Slot& out = h->slots[h->desc.out_slot];
+    if (!have(h->desc.out_slot, false)) rc = fail(h, -6, "ian_autotune: run ian_grad_* once first");
+    for (auto& op : h->ops) {
+      if (rc) break;
+      if (op.d.segment != IAN_SEG_DEC || !op.bwd.valid || op.edge) continue;
+      if (!have(op.d.dst, true)) {
+        rc = fail(h, -6, "ian_autotune: run ian_grad_* once first");
+        break;
+      }
+      TgChoice best;
+      float ms = 0;
+      rc = tune_layer(h, op.bwd, 1, st, [&]() { return run_decoder_backward(h, 0, out.w / 2 - 2, out.h / 2 - 2, out.w / 2 + 2, out.h / 2 + 2, nullptr, st); }, &best, &ms);
+      if (!rc && verbose)
+        fprintf(stderr, "[ian_autotune] n=1 bwd %-14s -> tile %s, max K-steps/item %d : chain %.1f us\n", op.name.c_str(),
+                cfg_names[best.cfg], best.max_steps, ms * 1e3);
+    }
+  }
+  h->prof = prof;
+  return rc;
+}
+
 int ian_grad_rgb(ian_handle* h, int32_t c1, int32_t r1, int32_t c2, int32_t r2, const float* rgb, const float* z,
                  float* dz, void* stream) {
   if (!rgb) return fail(h, -1, "rgb is null");
@@ -1169,6 +1347,8 @@ int ian_set_option(ian_handle* h, const char* key, int32_t value) {
   else if (k == "tg_no_split_items") h->opt.tg_no_split_items = value;
   else if (k == "tg_split") h->opt.tg_split = value;
   else if (k == "tg_xcd_group") h->opt.tg_xcd_group = std::max(1, value);
+  else if (k == "tg_prefer_nosplit") h->opt.tg_prefer_nosplit = value;
+  else if (k == "tg_nosplit_min_out") h->opt.tg_nosplit_min_out = value;
   else return fail(h, -1, "unknown option '%s'", key);
   for (auto& op : h->ops) {  // schedules depend on the options
     free_schedules(op.fwd);

@@ -42,7 +42,7 @@ class ModelDesc(C.Structure):
 EXPORTS = (
     "ian_create", "ian_load_param", "ian_set_made_masks", "ian_finalize", "ian_encode", "ian_decode",
     "ian_encode_pre_iaf", "ian_iaf", "ian_reconstruct", "ian_grad_rgb", "ian_grad_light", "ian_read_slot", "ian_read_slot_grad",
-    "ian_profile_enable", "ian_profile_read", "ian_set_option", "ian_last_error", "ian_version", "ian_destroy",
+    "ian_profile_enable", "ian_profile_read", "ian_autotune", "ian_set_option", "ian_last_error", "ian_version", "ian_destroy",
 )
 
 _lib = None
@@ -79,6 +79,7 @@ def load_library():
     lib.ian_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
     lib.ian_set_option.argtypes = [vp, C.c_char_p, i32]
+    lib.ian_autotune.argtypes = [vp, i32, i32, vp]
     lib.ian_last_error.argtypes = [vp]
     lib.ian_last_error.restype = C.c_char_p
     lib.ian_version.restype = C.c_char_p
@@ -188,6 +189,9 @@ class Handle:
         ms, n, fl, tot = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
         self._check(self.lib.ian_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(fl), C.byref(tot)))
         return {"tapgemm_ms": ms.value, "tapgemm_launches": n.value, "tapgemm_flops": fl.value, "total_ms": tot.value}
+
+    def autotune(self, n, what=1, stream=None):
+        self._check(self.lib.ian_autotune(self._h, int(n), int(what), C.c_void_p(stream or 0)))
 
     def set_option(self, key, value):
         self._check(self.lib.ian_set_option(self._h, key.encode(), int(value)))
