@@ -125,4 +125,17 @@ hipError_t launch_deconv_out_bwd(const float* g, const float* w, float* dx, cons
 hipError_t launch_dact_nchw(float* g, const float* y, const float* scale, int n, int c, int hw, int act,
                             hipStream_t s);
 
+// identity-edge gradient hand-over: gd[p,c] (+)= gs[p,coff+c] * act'(y[p,c]) * scale[c]   (NHWC, strides ss / ds)
+hipError_t launch_grad_pass(const float* gs, int ss, int coff, float* gd, const float* y, int ds, const float* scale,
+                            long long npix, int C, int act, int accumulate, hipStream_t s);
+// backward of beta_layer x3 + concat
+struct BetaBwdArgs {
+  const float* v[3];      // forward values of the three 2-channel maps (after their sigmoid)
+  float* g[3];            // gradient buffers of the same maps (pre-epilogue of their producers)
+  const float* scale[3];  // producer scale vectors (or nullptr)
+  int act[3];             // producer activations
+  int accumulate[3];
+};
+hipError_t launch_beta_bwd(const float* gout, const BetaBwdArgs& a, int n, int hw, int rs, hipStream_t s);
+
 }  // namespace ian

@@ -856,6 +856,34 @@ int tune_layer(ian_handle* h, TgLayer& L, int nimg, hipStream_t st, F&& run, TgC
   return 0;
 }
 
+// ----- autotune cache: IAN_TUNE_CACHE=<file> makes ian_autotune reuse / record its per-(batch, direction, layer)
+// choices, so that repeated processes (e.g. the rocprofv3 passes of one profile) run the very same kernels.
+typedef std::map<std::string, TgChoice> TuneCache;
+std::string tune_key(int n, const char* dir, const std::string& name) { return std::to_string(n) + " " + dir + " " + name; }
+void tune_cache_load(TuneCache& c) {
+  const char* path = getenv("IAN_TUNE_CACHE");
+  if (!path) return;
+  FILE* f = fopen(path, "r");
+  if (!f) return;
+  char dir[16], name[256];
+  int n, cfg, ms;
+  while (fscanf(f, "%d %15s %255s %d %d", &n, dir, name, &cfg, &ms) == 5) {
+    TgChoice ch;
+    ch.cfg = cfg;
+    ch.max_steps = ms;
+    c[tune_key(n, dir, name)] = ch;
+  }
+  fclose(f);
+}
+void tune_cache_store(const TuneCache& c) {
+  const char* path = getenv("IAN_TUNE_CACHE");
+  if (!path) return;
+  FILE* f = fopen(path, "w");
+  if (!f) return;
+  for (auto& kv : c) fprintf(f, "%s %d %d\n", kv.first.c_str(), kv.second.cfg, kv.second.max_steps);
+  fclose(f);
+}
+
 // stage a caller buffer (host or device) into a device pointer; returns pointer to use
 int stage_in(ian_handle* h, const float* src, size_t count, float** buf, size_t* cap, const float** out,
              hipStream_t st) {
@@ -946,53 +974,125 @@ struct TotalTimer {  // whole-call device time when profiling
 };
 
 // ----- latent-brush backward (API.py:59,64): reverse sweep over the decoder ops --------------------------
-// Gradient buffers hold dL/d(pre-epilogue value) of the slot's producer, so each backward tapgemm's epilogue
-// (TG_EPI_BWD) multiplies by act'(y)*scale of the NEXT producer upstream and no separate elementwise pass runs.
+// Gradient buffers (Slot::g) hold dL/d(pre-epilogue value) of the slot's producer, so each backward tapgemm's
+// epilogue (TG_EPI_BWD) multiplies by act'(y)*scale of the producer of ITS output slot and no separate
+// elementwise pass runs on the GEMM edges.  The decoder graph of the full IAN is a DAG (residual adds, the
+// shared feature map of the RGB-Beta head, concat): the ops are visited in reverse topological order and a slot
+// that has more than one consumer accumulates (the epilogue's `res` input / the accumulate flag of the
+// identity-edge kernels), "touched" recording whether a contribution already arrived in this sweep.
+struct ProducerEpi {
+  const float* scale = nullptr;
+  const float* yfwd = nullptr;
+  int act = IAN_ACT_NONE;
+  int scale_period = 0;
+};
+
 int run_decoder_backward(ian_handle* h, int mode, int c1, int r1, int c2, int r2, const float* d_rgb, hipStream_t st) {
   std::vector<OpPlan*> dec;
   for (auto& op : h->ops)
     if (op.d.segment == IAN_SEG_DEC) dec.push_back(&op);
   if (dec.empty()) return fail(h, -8, "no decoder ops");
-  // supported graph: a single chain DENSE -> DECONV5S2* -> DECONV5S2(edge) (IAN_simple decoder)
-  for (size_t i = 0; i < dec.size(); ++i) {
-    const int k = dec[i]->d.kind;
-    const bool ok = (k == IAN_OP_DENSE || k == IAN_OP_DECONV5S2) && dec[i]->d.src2 < 0 &&
-                    (i == 0 || dec[i]->d.src == dec[i - 1]->d.dst);
-    if (!ok) return fail(h, -9, "imgrad: backward is implemented for DENSE/DECONV5S2 chains only (op '%s')", dec[i]->name.c_str());
-  }
+  const int nslots = (int)h->slots.size();
+  std::vector<OpPlan*> prod(nslots, nullptr);
+  for (OpPlan* op : dec) prod[op->d.dst] = op;
   OpPlan& last = *dec.back();
+  if (last.d.dst != h->desc.out_slot) return fail(h, -9, "imgrad: the last decoder op does not produce l_out");
   Slot& out = h->slots[last.d.dst];
   const int H = out.h, W = out.w;
-  if (!(last.d.kind == IAN_OP_DECONV5S2 && last.edge)) return fail(h, -9, "imgrad: last decoder op must be the image deconv");
   if (c1 < 0 || r1 < 0 || c2 > W || r2 > H) return fail(h, -7, "patch (%d,%d,%d,%d) outside the %dx%d image", c1, r1, c2, r2, W, H);
   if (!h->d_gseed) HIPCHK(h, hipMalloc((void**)&h->d_gseed, (size_t)3 * H * W * sizeof(float)));
-  HIPCHK(h, launch_patch_seed(out.d, d_rgb, h->d_gseed, H, W, c1, r1, c2, r2, mode, st));
-  // gradient wrt dec_out's pre-activation
-  HIPCHK(h, launch_dact_nchw(h->d_gseed, out.d, last.d_scale, 1, out.c, H * W, last.d.act, st));
-  // dec_out backward -> gradient wrt pre-epilogue value of the previous op
+  HIPCHK(h, launch_patch_seed(out.d, d_rgb, h->d_gseed, H, W, c1, r1, c2, r2, mode, st));  // dL/dX_hat, NCHW
+
+  std::vector<char> touched(nslots, 0);
+  auto epi_of = [&](int slot) {  // what turns a value-gradient of `slot` into its producer's pre-epilogue gradient
+    ProducerEpi e;
+    OpPlan* p = prod[slot];
+    if (!p) return e;
+    Slot& s = h->slots[slot];
+    e.scale = p->d_scale;
+    e.act = p->d.act;
+    e.yfwd = (e.act != IAN_ACT_NONE) ? s.d : nullptr;
+    // a dense producer's batch-norm is per feature = per (pixel, channel) of the map it is reshaped to
+    e.scale_period = (p->d.kind == IAN_OP_DENSE && s.h * s.w > 1) ? (int)s.per_image() : 0;
+    return e;
+  };
+  auto pass_to = [&](const float* gs, int ss, int coff, int slot, int C) -> int {
+    Slot& t = h->slots[slot];
+    int rc = ensure_slot(h, slot, 1, true);
+    if (rc) return rc;
+    ProducerEpi e = epi_of(slot);
+    if (e.scale_period) return fail(h, -9, "imgrad: identity edge into a per-feature batch-norm is not supported");
+    HIPCHK(h, launch_grad_pass(gs, ss, coff, t.g, e.yfwd, t.cs, e.scale, (long long)t.h * t.w, C, e.act, touched[slot], st));
+    touched[slot] = 1;
+    return 0;
+  };
+
   for (int i = (int)dec.size() - 1; i >= 0; --i) {
     OpPlan& op = *dec[i];
-    Slot& in = h->slots[op.d.src];
+    const int kind = op.d.kind;
     int rc;
-    if ((rc = ensure_slot(h, op.d.src, 1, true))) return rc;
-    OpPlan* prev = i > 0 ? dec[i - 1] : nullptr;
-    TgEpilogue e;
-    e.scale = prev ? prev->d_scale : nullptr;
-    e.shift = nullptr; e.res = nullptr;
-    e.yfwd = prev ? in.d : nullptr;
-    e.act = prev ? prev->d.act : IAN_ACT_NONE;
-    e.mode = TG_EPI_BWD;
-    // a dense producer's batch-norm is per feature = per (pixel, channel) of the map it is reshaped to
-    e.scale_period = (prev && prev->d.kind == IAN_OP_DENSE && in.h * in.w > 1) ? (int)in.per_image() : 0;
-    if (op.edge) {
+    if (kind == IAN_OP_BETA) {  // IAN.py:207
+      const int srcs[3] = {op.d.src, op.d.src2, op.d.src3};
+      BetaBwdArgs a;
+      for (int c = 0; c < 3; ++c) {
+        Slot& m = h->slots[srcs[c]];
+        if ((rc = ensure_slot(h, srcs[c], 1, true))) return rc;
+        ProducerEpi e = epi_of(srcs[c]);
+        a.v[c] = m.d; a.g[c] = m.g; a.scale[c] = e.scale; a.act[c] = e.act; a.accumulate[c] = touched[srcs[c]];
+        touched[srcs[c]] = 1;
+      }
+      Slot& m0 = h->slots[srcs[0]];
+      HIPCHK(h, launch_beta_bwd(h->d_gseed, a, 1, m0.h * m0.w, m0.cs, st));
+      continue;
+    }
+    if (kind == IAN_OP_DECONV5S2 && op.edge) {  // image-producing deconv (IAN_simple dec_out)
+      if (op.d.dst != h->desc.out_slot) return fail(h, -9, "imgrad: edge deconv '%s' must produce l_out", op.name.c_str());
+      Slot& in = h->slots[op.d.src];
+      if (touched[op.d.src]) return fail(h, -9, "imgrad: '%s' input has several consumers", op.name.c_str());
+      if ((rc = ensure_slot(h, op.d.src, 1, true))) return rc;
+      HIPCHK(h, launch_dact_nchw(h->d_gseed, out.d, op.d_scale, 1, out.c, H * W, op.d.act, st));
+      ProducerEpi e = epi_of(op.d.src);
+      if (e.scale_period) return fail(h, -9, "imgrad: per-feature batch-norm directly under the image deconv");
       HIPCHK(h, launch_deconv_out_bwd(h->d_gseed, op.d_edge_w, in.g, e.yfwd, e.scale, 1, op.d.in_h, op.d.in_w, in.cs,
                                       op.d.cout, e.act, st));
-    } else {
-      Slot& o = h->slots[op.d.dst];
-      const int ystride = (op.d.kind == IAN_OP_DENSE) ? (int)in.per_image() : in.cs;
-      if ((rc = run_tapgemm(h, op.bwd, 1, o.g, in.g, ystride, e, st))) return rc;
+      touched[op.d.src] = 1;
+      continue;
+    }
+    if (!touched[op.d.dst]) return fail(h, -9, "imgrad: no gradient reached the output of '%s'", op.name.c_str());
+    Slot& o = h->slots[op.d.dst];
+    switch (kind) {
+      case IAN_OP_DENSE:
+      case IAN_OP_DECONV5S2:
+      case IAN_OP_MDC3: {
+        if (!op.bwd.valid) return fail(h, -9, "imgrad: op '%s' has no backward-data form", op.name.c_str());
+        Slot& in = h->slots[op.d.src];
+        if ((rc = ensure_slot(h, op.d.src, 1, true))) return rc;
+        ProducerEpi pe = epi_of(op.d.src);
+        TgEpilogue e;
+        e.scale = pe.scale; e.shift = nullptr; e.yfwd = pe.yfwd; e.act = pe.act; e.scale_period = pe.scale_period;
+        e.res = touched[op.d.src] ? in.g : nullptr;
+        e.mode = TG_EPI_BWD;
+        const int ystride = (kind == IAN_OP_DENSE) ? (int)in.per_image() : in.cs;
+        if ((rc = run_tapgemm(h, op.bwd, 1, o.g, in.g, ystride, e, st))) return rc;
+        touched[op.d.src] = 1;
+        if (kind == IAN_OP_MDC3 && op.d.src2 >= 0)  // residual operand of the fused ElemwiseSum: identity edge
+          if ((rc = pass_to(o.g, o.cs, 0, op.d.src2, o.c))) return rc;
+        break;
+      }
+      case IAN_OP_AFFINE:  // stand-alone BatchNorm(+nonlinearity): its g already is dL/d(input value)
+        if ((rc = pass_to(o.g, o.cs, 0, op.d.src, o.c))) return rc;
+        break;
+      case IAN_OP_CONCAT: {
+        const int ca = h->slots[op.d.src].c, cb = h->slots[op.d.src2].c;
+        if ((rc = pass_to(o.g, o.cs, 0, op.d.src, ca))) return rc;
+        if ((rc = pass_to(o.g, o.cs, ca, op.d.src2, cb))) return rc;
+        break;
+      }
+      default:
+        return fail(h, -9, "imgrad: backward of op kind %d ('%s') is not implemented", kind, op.name.c_str());
     }
   }
+  if (!touched[h->desc.z_slot]) return fail(h, -9, "imgrad: no gradient reached the latent");
   return 0;
 }
 
@@ -1208,6 +1308,9 @@ int ian_autotune(ian_handle* h, int32_t n, int32_t what, void* stream) {
   h->prof = false;
   const bool verbose = getenv("IAN_DEBUG") != nullptr;
   static const char* cfg_names[TG_NCONFIG] = {"128x128", "128x64", "64x64", "32x128", "256x128", "128x32"};
+  TuneCache cache;
+  tune_cache_load(cache);
+  bool cache_dirty = false;
   auto have = [&](int slot, bool grad) {
     if (slot < 0) return true;
     const Slot& s = h->slots[slot];
@@ -1223,7 +1326,15 @@ int ian_autotune(ian_handle* h, int32_t n, int32_t what, void* stream) {
       TgChoice best;
       float ms = 0;
       OpPlan* opp = &op;
+      auto hit = cache.find(tune_key(n, "fwd", op.name));
+      if (hit != cache.end()) {
+        op.fwd.choice[n] = hit->second;
+        free_schedule_for(op.fwd, n);
+        continue;
+      }
+      cache_dirty = true;
       if ((rc = tune_layer(h, op.fwd, n, st, [&]() { return run_op_fwd(h, *opp, n, st); }, &best, &ms))) break;
+      cache[tune_key(n, "fwd", op.name)] = best;
       if (verbose)
         fprintf(stderr, "[ian_autotune] n=%d fwd %-14s -> tile %s, max K-steps/item %d : %.1f us (%.1f TF/s)\n", n,
                 op.name.c_str(), cfg_names[best.cfg], best.max_steps, ms * 1e3,
@@ -1246,13 +1357,22 @@ int ian_autotune(ian_handle* h, int32_t n, int32_t what, void* stream) {
       }
       TgChoice best;
       float ms = 0;
+      auto hit = cache.find(tune_key(1, "bwd", op.name));
+      if (hit != cache.end()) {
+        op.bwd.choice[1] = hit->second;
+        free_schedule_for(op.bwd, 1);
+        continue;
+      }
+      cache_dirty = true;
       rc = tune_layer(h, op.bwd, 1, st, [&]() { return run_decoder_backward(h, 0, out.w / 2 - 2, out.h / 2 - 2, out.w / 2 + 2, out.h / 2 + 2, nullptr, st); }, &best, &ms);
+      if (!rc) cache[tune_key(1, "bwd", op.name)] = best;
       if (!rc && verbose)
         fprintf(stderr, "[ian_autotune] n=1 bwd %-14s -> tile %s, max K-steps/item %d : chain %.1f us\n", op.name.c_str(),
                 cfg_names[best.cfg], best.max_steps, ms * 1e3);
     }
   }
   h->prof = prof;
+  if (!rc && cache_dirty) tune_cache_store(cache);
   return rc;
 }
 

@@ -93,18 +93,38 @@ hipError_t launch_conv1_nchw(const float* x, const float* w, const float* scale,
 
 // ------------------------------------------------------------------------------------------------
 // dec_out (IAN_simple.py:171-181): x NHWC [n,H,W,Cin] -> y NCHW [n,Cout<=4,2H,2W], 5x5 s2 transposed conv.
-// Block = 16x16 output tile = 8x8 input pixels (+1 halo) staged in LDS with a Cin+4 pixel stride
-// (conflict-free ds_read_b128 across pixels); wave = output parity class (uniform tap list 9/6/6/4,
-// weights arrive through scalar loads), lane = position in the 8x8 grid.
+// Block = 16x16 output tile = 8x8 input pixels (+1 halo) staged in LDS with a Cin+4 pixel stride.
+// Each of the 4 waves owns a quarter of the input channels and computes ALL four output-parity classes
+// (25 taps: balanced, unlike one 9/6/6/4-tap class per wave) for the 64 input positions, one per lane; the
+// filter taps of its channel slice are wave-uniform and arrive through scalar loads.  The lane -> position map
+// follows the hardware's ds_read_b128 service groups ({0-3,12-15,20-27},{4-11,16-19,28-31},+32): a group covers
+// rows (g, g+4) of the 8x8 grid, whose 16 pixels fall into 16 distinct 16-byte bank slots for the 10-pixel row
+// pitch (10*4 = 8 mod 16) -> conflict-free fragment reads.  The four channel-slice partials meet in LDS and
+// are written as NCHW rows of 16 consecutive pixels.
 // w packed [ky*5+kx][4][Cin] already holding the (possibly flipped) reference filter.
 // ------------------------------------------------------------------------------------------------
-template <int CIN>
+__device__ __forceinline__ void dq_lane_to_pos(int lane, int& qy, int& qx) {
+  const int l5 = lane & 31;
+  const bool g1 = (l5 >= 4 && l5 < 12) || (l5 >= 16 && l5 < 20) || l5 >= 28;
+  const int pos = g1 ? (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16)) : (l5 < 4 ? l5 : (l5 < 16 ? l5 - 8 : l5 - 12));
+  const int gi = (lane >> 5) * 2 + (g1 ? 1 : 0);
+  qy = gi + 4 * (pos >> 3);
+  qx = pos & 7;
+}
+__device__ __forceinline__ int dq_pos_to_lane(int qy, int qx) {
+  const int gi = qy & 3, pos = (qy >> 2) * 8 + qx;
+  const int l5 = (gi & 1) ? (pos < 8 ? pos + 4 : (pos < 12 ? pos + 8 : pos + 16)) : (pos < 4 ? pos : (pos < 8 ? pos + 8 : pos + 12));
+  return (gi >> 1) * 32 + l5;
+}
+
+template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void deconv_out_nchw_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float* __restrict__ y,
-                                                              int H, int W, int Cout, int act) {
+                                                              int H, int W, int act) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  constexpr int PS = CIN + 4;  // padded pixel stride
+  constexpr int PS = CIN + 4;   // padded pixel stride
+  constexpr int CW = CIN / 4;   // channels per wave
   const int tiles_x = W >> 3;
   const int n = blockIdx.y, ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
   const int iy0 = ty * 8 - 1, ix0 = tx * 8 - 1;
@@ -118,55 +138,85 @@ __global__ __launch_bounds__(256) void deconv_out_nchw_kernel(const float* __res
     *reinterpret_cast<float4*>(sm + pix * PS + c4) = v;
   }
   __syncthreads();
-  const int cls = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int py = cls >> 1, px = cls & 1;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int qy = lane >> 3, qx = lane & 7;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-  // oy = 2*iy - 2 + ky  =>  ky = py + 2 - 2*dy with iy = qy + dy ; even: dy in {1,0,-1}, odd: dy in {1,0}
-  for (int ky = py; ky < 5; ky += 2) {
-    const int dy = (py + 2 - ky) / 2;
-    for (int kx = px; kx < 5; kx += 2) {
-      const int dx = (px + 2 - kx) / 2;
-      const float* xs = sm + ((qy + dy + 1) * 10 + (qx + dx + 1)) * PS;
-      const float* wt = w + (size_t)(ky * 5 + kx) * 4 * CIN;
-#pragma unroll 8
-      for (int c = 0; c < CIN; c += 4) {
+  int qy, qx;
+  dq_lane_to_pos(lane, qy, qx);
+  const int cbase = wave * CW;
+  float acc[4][COUT];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[k][co] = 0.f;
+  // oy = 2*iy - 2 + ky  =>  class py = ky&1, input row iy = qy + dy with dy = (py + 2 - ky)/2
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky) {
+    const int py = ky & 1, dy = (py + 2 - ky) / 2;
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) {
+      const int px = kx & 1, dx = (px + 2 - kx) / 2;
+      const int cls = py * 2 + px;
+      const float* xs = sm + ((qy + dy + 1) * 10 + (qx + dx + 1)) * PS + cbase;
+      const float* wt = w + (size_t)(ky * 5 + kx) * 4 * CIN + cbase;  // wave-uniform -> scalar loads
+#pragma unroll
+      for (int c = 0; c < CW; c += 4) {
         const float4 xv = *reinterpret_cast<const float4*>(xs + c);
-        const float4 w0 = *reinterpret_cast<const float4*>(wt + c);
-        const float4 w1 = *reinterpret_cast<const float4*>(wt + CIN + c);
-        const float4 w2 = *reinterpret_cast<const float4*>(wt + 2 * CIN + c);
-        const float4 w3 = *reinterpret_cast<const float4*>(wt + 3 * CIN + c);
-        acc0 = fmaf(xv.x, w0.x, acc0); acc0 = fmaf(xv.y, w0.y, acc0); acc0 = fmaf(xv.z, w0.z, acc0); acc0 = fmaf(xv.w, w0.w, acc0);
-        acc1 = fmaf(xv.x, w1.x, acc1); acc1 = fmaf(xv.y, w1.y, acc1); acc1 = fmaf(xv.z, w1.z, acc1); acc1 = fmaf(xv.w, w1.w, acc1);
-        acc2 = fmaf(xv.x, w2.x, acc2); acc2 = fmaf(xv.y, w2.y, acc2); acc2 = fmaf(xv.z, w2.z, acc2); acc2 = fmaf(xv.w, w2.w, acc2);
-        acc3 = fmaf(xv.x, w3.x, acc3); acc3 = fmaf(xv.y, w3.y, acc3); acc3 = fmaf(xv.z, w3.z, acc3); acc3 = fmaf(xv.w, w3.w, acc3);
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+          const float4 wv = *reinterpret_cast<const float4*>(wt + co * CIN + c);
+          float a = acc[cls][co];
+          a = fmaf(xv.x, wv.x, a);
+          a = fmaf(xv.y, wv.y, a);
+          a = fmaf(xv.z, wv.z, a);
+          a = fmaf(xv.w, wv.w, a);
+          acc[cls][co] = a;
+        }
       }
     }
   }
+  __syncthreads();  // the input tile is dead: reuse LDS for the partials [wave][cls][co][lane]
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) sm[((wave * 4 + k) * COUT + co) * 64 + lane] = acc[k][co];
+  __syncthreads();
   const int OH = 2 * H, OW = 2 * W;
-  const int oy = 2 * (ty * 8 + qy) + py, ox = 2 * (tx * 8 + qx) + px;
-  const float a[4] = {acc0, acc1, acc2, acc3};
-  for (int co = 0; co < Cout; ++co) {
+  const int oyl = threadIdx.x >> 4, oxl = threadIdx.x & 15;  // 16x16 output tile, rows of 16 consecutive pixels
+  const int cls = (oyl & 1) * 2 + (oxl & 1);
+  const int src = dq_pos_to_lane(oyl >> 1, oxl >> 1);
+  const int oy = ty * 16 + oyl, ox = tx * 16 + oxl;
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) {
+    float v = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) v += sm[((wv * 4 + cls) * COUT + co) * 64 + src];
     const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
-    y[((size_t)(n * Cout + co) * OH + oy) * OW + ox] = m_act(a[co] * sc + sh, act);
+    y[((size_t)(n * COUT + co) * OH + oy) * OW + ox] = m_act(v * sc + sh, act);
   }
+}
+
+template <int CIN>
+static hipError_t launch_deconv_out_cin(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                                        int n, int H, int W, int Cout, int act, hipStream_t s) {
+  dim3 grid((H / 8) * (W / 8), n);
+  const size_t lds = (size_t)100 * (CIN + 4) * sizeof(float);
+  switch (Cout) {
+    case 1: hipLaunchKernelGGL((deconv_out_nchw_kernel<CIN, 1>), grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, act); break;
+    case 2: hipLaunchKernelGGL((deconv_out_nchw_kernel<CIN, 2>), grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, act); break;
+    case 3: hipLaunchKernelGGL((deconv_out_nchw_kernel<CIN, 3>), grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, act); break;
+    case 4: hipLaunchKernelGGL((deconv_out_nchw_kernel<CIN, 4>), grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, act); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_deconv_out_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
                                   int n, int H, int W, int Cin, int Cout, int act, hipStream_t s) {
-  if (Cout > 4 || (H & 7) || (W & 7)) return hipErrorInvalidValue;
-  dim3 grid((H / 8) * (W / 8), n);
-  const size_t lds = (size_t)100 * (Cin + 4) * sizeof(float);
-  if (Cin == 128)
-    hipLaunchKernelGGL(deconv_out_nchw_kernel<128>, grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, Cout, act);
-  else if (Cin == 64)
-    hipLaunchKernelGGL(deconv_out_nchw_kernel<64>, grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, Cout, act);
-  else if (Cin == 256)
-    hipLaunchKernelGGL(deconv_out_nchw_kernel<256>, grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, Cout, act);
-  else
-    return hipErrorInvalidValue;
-  return hipGetLastError();
+  if (Cout > 4 || Cout < 1 || (H & 7) || (W & 7)) return hipErrorInvalidValue;
+  if (Cin == 128) return launch_deconv_out_cin<128>(x, w, scale, shift, y, n, H, W, Cout, act, s);
+  if (Cin == 64) return launch_deconv_out_cin<64>(x, w, scale, shift, y, n, H, W, Cout, act, s);
+  if (Cin == 256) return launch_deconv_out_cin<256>(x, w, scale, shift, y, n, H, W, Cout, act, s);
+  return hipErrorInvalidValue;
 }
 
 // backward-data of dec_out for the latent brush (API.py:59,64):
@@ -392,6 +442,74 @@ hipError_t launch_dact_nchw(float* g, const float* y, const float* scale, int n,
   const long long total = (long long)n * c * hw;
   hipLaunchKernelGGL(dact_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, y, scale, n, c, hw,
                      act);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// latent-brush backward through the non-GEMM nodes of the full IAN decoder (IAN.py:139-207)
+// ------------------------------------------------------------------------------------------------
+// Gradient hand-over along an identity edge (ElemwiseSum residual layers.py:412-416, stand-alone BatchNorm
+// layers.py:412, ConcatLayer IAN.py:201): the value-gradient arriving in gs (channels coff..coff+C of an NHWC
+// buffer with pixel stride ss) becomes the gradient wrt the pre-epilogue value of the target slot's producer:
+//   gd[p,c] (+)= gs[p,coff+c] * act'(y[p,c]) * scale[c]
+__global__ __launch_bounds__(256) void grad_pass_kernel(const float* __restrict__ gs, int ss, int coff,
+                                                        float* __restrict__ gd, const float* __restrict__ y, int ds,
+                                                        const float* __restrict__ scale, long long npix, int C,
+                                                        int act, int accumulate) {
+  const long long total = npix * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long p = i / C;
+    const int c = (int)(i % C);
+    float v = gs[p * ss + coff + c];
+    if (y) v *= m_dact(y[p * ds + c], act);
+    if (scale) v *= scale[c];
+    float* o = gd + p * ds + c;
+    *o = accumulate ? *o + v : v;
+  }
+}
+hipError_t launch_grad_pass(const float* gs, int ss, int coff, float* gd, const float* y, int ds, const float* scale,
+                            long long npix, int C, int act, int accumulate, hipStream_t s) {
+  long long total = npix * C;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(grad_pass_kernel, dim3(blocks), dim3(256), 0, s, gs, ss, coff, gd, y, ds, scale, npix, C, act,
+                     accumulate);
+  return hipGetLastError();
+}
+
+// backward of beta_layer x3 + concat (layers.py:397-408, IAN.py:207): out_c = 2a/(a+b+1e-8) - 1 with (a,b) the two
+// channels of map c.  gout NCHW [n,3,hw] -> gradient wrt the pre-activation of each map's producer
+// (times act'(v) * scale of that producer); maps are NHWC with pixel stride rs.
+__global__ __launch_bounds__(256) void beta_bwd_kernel(const float* __restrict__ gout, BetaBwdArgs a, int n, int hw,
+                                                       int rs) {
+  const long long total = (long long)n * hw;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int b = (int)(i / hw), p = (int)(i % hw);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float va = a.v[c][i * rs + 0], vb = a.v[c][i * rs + 1];
+    const float g = gout[((size_t)b * 3 + c) * hw + p];
+    const float den = va + vb + 1e-8f;
+    const float inv2 = 2.f / (den * den);
+    float ga = g * inv2 * (vb + 1e-8f);
+    float gb = -g * inv2 * va;
+    ga *= m_dact(va, a.act[c]) * (a.scale[c] ? a.scale[c][0] : 1.f);
+    gb *= m_dact(vb, a.act[c]) * (a.scale[c] ? a.scale[c][1] : 1.f);
+    float* o = a.g[c] + i * rs;
+    if (a.accumulate[c]) {
+      o[0] += ga;
+      o[1] += gb;
+    } else {
+      o[0] = ga;
+      o[1] = gb;
+    }
+  }
+}
+hipError_t launch_beta_bwd(const float* gout, const BetaBwdArgs& a, int n, int hw, int rs, hipStream_t s) {
+  const long long total = (long long)n * hw;
+  hipLaunchKernelGGL(beta_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gout, a, n, hw, rs);
   return hipGetLastError();
 }
 
