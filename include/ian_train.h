@@ -1,0 +1,130 @@
+/* ian_train.h -- C ABI of the training-step building blocks of libian.so.
+ *
+ * The reference's training step (train_IAN.py:47-352 make_training_functions) is a Python function that wires
+ * Lasagne layers (layers.py: DeconvLayer, MDCL, MinibatchLayer, beta_layer, MADE/IAFLayer; Lasagne: Conv2DDNNLayer,
+ * DenseLayer, batch_norm) into one Theano graph and lets Theano differentiate it.  Here the same wiring is done by
+ * the Python host (neural_photo_editor_amd/trainer.py) over the entry points below:
+ *   - ian_layer_*: one object per linear Lasagne layer (conv / transposed conv / MDCL / dense) owning its packed
+ *     weights, with forward, backward-data and backward-weight -- the three cuDNN/GEMM calls Theano would emit;
+ *   - ian_k_*:     the element-wise / reduction ops around them (batch-statistics batch-norm, activations,
+ *     MinibatchLayer, losses, Adam ...), one HIP launch sequence each.
+ * Conventions: every pointer is DEVICE memory owned by the caller (torch tensors are only the container);
+ * activations are NHWC float32 with the channel (pixel) stride rounded up to a multiple of 32; parameters and their
+ * gradients are in the REFERENCE layout (Theano shapes) so that checkpoints and optimiser state
+ * are layout independent; all work is ordered on `stream`; return 0 / negative, text via ian_k_last_error().
+ * All reductions use fixed summation orders: results are bitwise reproducible run to run.
+ */
+#ifndef IAN_TRAIN_H_
+#define IAN_TRAIN_H_
+
+#include <stdint.h>
+
+#include "ian.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ian_layer ian_layer;
+
+/* Build a layer from the geometry fields of an ian_op_desc (kind, cin, cout, in_h, in_w, flat, unflat, scales).
+   kind CONV5S2 : Conv2D(DNN)Layer 5x5/s2/p2, W (Cout,Cin,5,5)                      IAN.py:71-110
+        DECONV5S2: layers.py:436-483 DeconvLayer, W (Cin,Cout,5,5)                   IAN.py:139-181
+        MDC3    : layers.py:207-258 MDCL, params W (Cout,Cin,3,3), coeff_base, then one coefficient per scale
+        DENSE   : DenseLayer, W (in,out)                                             IAN.py:114-134
+   Parameter order for ian_layer_set_params / ian_layer_backward_weight: W first, then (MDC3) the coefficients in
+   the order coeff_base, scales[0], scales[1], ... (scale 0 = the 1x1 mean branch). */
+int ian_layer_create(const ian_op_desc* desc, int32_t deconv_flip, ian_layer** out);
+/* Number of parameter tensors and elements of each (reference layout). */
+int32_t ian_layer_num_params(ian_layer* l);
+int64_t ian_layer_param_numel(ian_layer* l, int32_t which);
+/* (Re)pack the current parameter values (device pointers, reference layout) into the kernel layouts.  Call after
+   every optimiser update. */
+int ian_layer_set_params(ian_layer* l, const float* const* params, int32_t nparams, void* stream);
+/* y = act(x (*) W + bias + res).  bias / res may be NULL; bias is indexed by output channel (internal order).
+   y_stride: pixel stride of y (0 = round_up(cout,32)). */
+int ian_layer_forward(ian_layer* l, const float* x, int32_t n, float* y, int32_t y_stride, const float* bias,
+                      const float* res, int32_t act, void* stream);
+/* dx (+)= dy (*) W^T   (gradient wrt the layer input; dy is the gradient wrt the pre-activation output) */
+int ian_layer_backward_data(ian_layer* l, const float* dy, int32_t n, float* dx, int32_t dx_stride, int32_t accumulate,
+                            void* stream);
+/* dparams[i] (+)= d loss / d param_i in the reference layout (same order as set_params). */
+int ian_layer_backward_weight(ian_layer* l, const float* x, const float* dy, int32_t n, float* const* dparams,
+                              int32_t nparams, int32_t accumulate, void* stream);
+const char* ian_layer_last_error(ian_layer* l);
+void ian_layer_destroy(ian_layer* l);
+
+/* ---- element-wise / reduction ops (names follow the reference construct they implement) ------------------- */
+const char* ian_k_last_error(void);
+/* per-channel sums over NHWC rows, two-stage: workspace >= nchunks*2*C floats, sums = [2][C].
+   mode 0: (sum x, sum x^2) of x.   mode 1: g = x*act'(a): (sum g, sum g*xhat), xhat=(y-mean)*inv_std.
+   mode 2: g = x*act'(a): (sum g, -).                                   batch_norm / bias gradients (App. B.3) */
+int ian_k_colstats(int32_t mode, const float* x, const float* a, const float* y, const float* mean, const float* inv_std,
+                   int64_t rows, int32_t C, int32_t stride, int32_t act, float* workspace, int32_t nchunks, float* sums,
+                   void* stream);
+/* batch statistics -> mean, inv_std = 1/sqrt(var+eps), scale = gamma*inv_std, shift = beta - mean*scale */
+int ian_k_bn_make_affine(const float* sums, float count, float eps, const float* gamma, const float* beta, int32_t C,
+                         float* mean, float* inv_std, float* scale, float* shift, void* stream);
+/* y = act(x*scale + shift) per channel (scale/shift may be NULL) */
+int ian_k_affine(const float* x, float* y, const float* scale, const float* shift, int64_t rows, int32_t C, int32_t stride,
+                 int32_t act, void* stream);
+/* backward of [batch_norm ->] nonlinearity: dy = scale*(g - s1/N - xhat*s2/N), g = dA*act'(a); sums NULL: dy = g */
+int ian_k_bn_bwd(const float* dA, const float* a, const float* y, const float* mean, const float* inv_std,
+                 const float* scale, const float* sums, float count, float* dy, int64_t rows, int32_t C, int32_t stride,
+                 int32_t act, void* stream);
+int ian_k_axpy(float alpha, const float* x, float* y, int64_t n, int32_t accumulate, void* stream);
+int ian_k_gather(const float* src, const int32_t* map, float* dst, int64_t count, void* stream);
+int ian_k_nchw_to_nhwc(const float* src, float* dst, int32_t n, int32_t hw, int32_t c, int32_t stride, void* stream);
+int ian_k_nhwc_to_nchw(const float* src, int32_t stride, float* dst, int32_t n, int32_t hw, int32_t c, void* stream);
+/* GlobalPoolLayer (IAN.py:209) */
+int ian_k_globalpool(const float* x, float* y, int32_t n, int32_t hw, int32_t C, int32_t xs, int32_t ys, void* stream);
+int ian_k_globalpool_bwd(const float* dy, float* dx, int32_t n, int32_t hw, int32_t C, int32_t xs, int32_t ys,
+                         int32_t accumulate, void* stream);
+/* MinibatchLayer (layers.py:486-524): weight normalisation (:494), pairwise-L1 kernel features (:507-520) */
+int ian_k_mb_weight(const float* theta, const float* lws, float* W, float* colscale, int32_t nin, int32_t ncol, void* stream);
+int ian_k_mb_weight_bwd(const float* theta, const float* colscale, const float* dW, float* dtheta, float* dlws, int32_t nin,
+                        int32_t ncol, int32_t accumulate, void* stream);
+int ian_k_mb_forward(const float* act_all, int32_t nall, int32_t as, int32_t row0, int32_t n, int32_t nk, int32_t nd,
+                     const float* bias, const float* feat, int32_t fs, int32_t fin, float* mb, int32_t ms, void* stream);
+int ian_k_mb_backward(const float* act_all, int32_t nall, int32_t as, int32_t row0, int32_t n, int32_t nk, int32_t nd,
+                      const float* df_all, int32_t dfs, float* dact, int32_t das, void* stream);
+/* `discrimi` DenseLayer(3, softmax, b=None) + categorical cross-entropy (IAN.py:210-216, train_IAN.py:228-250) */
+int ian_k_disc_head(const float* mb, int32_t ms, int32_t nfeat, const float* Wd, int32_t n, int32_t target0, int32_t target1,
+                    int32_t acc_target, float* p, float* loss, void* stream);
+int ian_k_disc_head_bwd(const float* p, const float* Wd, int32_t nfeat, int32_t n, int32_t t0, float w0, int32_t t1, float w1,
+                        float* dlogits, float* dmb, int32_t ms, void* stream);
+int ian_k_disc_head_wgrad(const float* mb, int32_t ms, int32_t nfeat, int32_t n, const float* dlogits, float* dWd,
+                          int32_t accumulate, void* stream);
+/* GaussianSampleLayer (layers.py:419-433) + KL terms (train_IAN.py:172) */
+int ian_k_sample(const float* mu, const float* ls, const float* eps, float* z0, float* klterm, int32_t n, int32_t d,
+                 int32_t stride, int32_t eps_stride, void* stream);
+int ian_k_sample_bwd(const float* mu, const float* ls, const float* eps, const float* dz0, float* dmu, float* dls, int32_t n,
+                     int32_t d, int32_t stride, int32_t eps_stride, float klw, void* stream);
+/* MADE x2 + IAFLayer (layers.py:641-650,735-853); wts = 6 pre-masked (in,out) matrices, bias = 6 vectors, order
+   mu_input, mu_output_W, mu_output_D, ls_input, ls_output_W, ls_output_D */
+int ian_k_made_iaf(const float* z0, float* z, const float* wts, const float* bias, int32_t n, int32_t d, int32_t zs,
+                   void* stream);
+int ian_k_made_iaf_bwd(const float* z0, const float* dz, float* dz0, const float* wts, const float* bias, int32_t n,
+                       int32_t d, int32_t zs, void* stream);
+/* beta_layer x3 + concat (layers.py:397-408, IAN.py:207) and ConcatLayer (IAN.py:201), forward and backward */
+int ian_k_beta(const float* R, const float* G, const float* B, float* y_nchw, int32_t n, int32_t hw, int32_t rs, void* stream);
+int ian_k_beta_bwd(const float* gout_nchw, const float* R, const float* G, const float* B, float* gR, float* gG, float* gB,
+                   int32_t n, int32_t hw, int32_t rs, int32_t act, void* stream);
+int ian_k_concat2(const float* a, int32_t ca, int32_t sa, const float* b, int32_t cb, int32_t sb, float* y, int32_t sy,
+                  int64_t npix, void* stream);
+/* gd[p,c] (+)= gs[p,coff+c] * act'(y[p,c])   (identity edges: concat / residual backward, sigmoid backward) */
+int ian_k_grad_pass(const float* gs, int32_t ss, int32_t coff, float* gd, const float* y, int32_t ds, int64_t npix,
+                    int32_t C, int32_t act, int32_t accumulate, void* stream);
+/* mode 0: pixel_loss 2|a-b+1e-8| (+ squared error), mode 1: squared error; da (+)= w * d/da; out[2] = scale * sums */
+int ian_k_pair_loss(const float* a, const float* b, float* da, int64_t rows, int32_t C, int32_t stride, int32_t mode, float w,
+                    int32_t accumulate, float* workspace, int32_t nblocks, float scale, float* out, void* stream);
+int ian_k_sum_rows(const float* x, int32_t n, int32_t width, float scale, float* out, void* stream);
+/* orthogonal regulariser (train_IAN.py:158-165) on W (A,B,K,K): vals[a] = sum|y_a|, dW += c * d/dW (dW may be NULL) */
+int ian_k_ortho(const float* W, float* dW, int32_t A, int32_t B, int32_t K, float c, float* vals, void* stream);
+/* lasagne.updates.adam (App. B.7) on a flat group */
+int ian_k_adam(float* p, const float* g, float* m, float* v, int64_t n, float a_t, float b1, float b2, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IAN_TRAIN_H_ */

@@ -138,4 +138,115 @@ struct BetaBwdArgs {
 };
 hipError_t launch_beta_bwd(const float* gout, const BetaBwdArgs& a, int n, int hw, int rs, hipStream_t s);
 
+// ---------------------------------------------------------------------------------------------
+// training step (train_IAN.py:47-352): backward-weight tap GEMM, parameter (re)packing, elementwise / reductions
+// ---------------------------------------------------------------------------------------------
+struct WgItem {  // one workgroup of tapwgrad: a (tap, Cout tile, Cin tile, pixel range) -> one partial-slab tile
+  int cls, tap;  // class index, GLOBAL tap index (== slab index of the forward packing)
+  int co0, ci0;
+  int m0, m1;    // contraction range over (image, qy, qx), multiples of 32 except the tail
+  int split;     // which partial slab
+  int pad;
+};
+struct WgParams {
+  const float* x;   // layer input, NHWC, pixel stride Cin
+  const float* dy;  // gradient wrt the layer's (pre-epilogue) output, NHWC, pixel stride dy_stride
+  float* partial;   // [nsplit][ntaps][CoutPad][CinPad]
+  const WgItem* items;
+  const TgClass* classes;
+  const TgTap* taps;
+  int M, IH, IW, Cin, qw_shift, qhw_shift, si, by, bx, so, OH, OW;
+  int dy_stride, CoutPad, CinPad;
+  long long slab_total;
+  unsigned x_bytes, dy_bytes;
+};
+enum WgConfig { WG_128x128 = 0, WG_32x128 = 1, WG_128x32 = 2 };
+hipError_t launch_tapwgrad(int cfg, const WgParams& p, int nitems, hipStream_t s);
+hipError_t launch_wgrad_reduce(const float* partial, long long slab_total, int nsplit, const int* inv, float* out,
+                               long long count, int accumulate, hipStream_t s);
+hipError_t launch_gather_pack(const float* src, const int* map, float* dst, long long count, hipStream_t s);
+
+constexpr int MDC_MAX_BRANCH = 5;  // base 3x3 + up to IAN_MAX_SCALES dilated branches
+struct MdcPackArgs {
+  const float* W;                      // (Cout,Cin,3,3) reference layout
+  const float* coeff[MDC_MAX_BRANCH];  // per-filter coefficients of the 3x3 branches: [0] = base, then dilations in order
+  const float* coeff_1x1;              // or nullptr
+  float* slab_f;                       // [ntaps][f_rows][f_cols]
+  float* slab_b;                       // [ntaps][b_rows][b_cols] (transposed)
+  int ntaps, cout, cin, nbranch, f_rows, f_cols, b_rows, b_cols;
+  int tap_start[48];                   // entries of tap t: [tap_start[t], tap_start[t+1])
+  unsigned char ent_branch[48], ent_pq[48];
+};
+struct MdcCoeffGrads {
+  float* d[MDC_MAX_BRANCH];
+  float* d1x1;
+};
+hipError_t launch_mdc_pack(const MdcPackArgs& a, hipStream_t s);
+hipError_t launch_mdc_unpack_grad(const MdcPackArgs& a, const float* dS, float* dW, const MdcCoeffGrads& g,
+                                  int accumulate, hipStream_t s);
+
+struct ColStatsArgs {
+  const float* x;  // mode 0: the tensor; modes 1,2: dA
+  const float* a;  // post-activation output (for act'), modes 1,2
+  const float* y;  // raw (pre-batch-norm) value, mode 1
+  const float* mean;
+  const float* inv_std;
+  float* partial;  // [nchunks][2][C]
+  long long rows;
+  int C, stride, mode, act;
+};
+hipError_t launch_colstats(const ColStatsArgs& a, int nchunks, float* sums, hipStream_t s);
+hipError_t launch_bn_make_affine(const float* sums, float count, float eps, const float* gamma, const float* beta,
+                                 int C, float* mean, float* inv_std, float* scale, float* shift, hipStream_t s);
+struct BnBwdArgs {
+  const float* dA;
+  const float* a;
+  const float* y;
+  const float* mean;
+  const float* inv_std;
+  const float* scale;
+  const float* sums;  // [2][C] (sum g, sum g*xhat) or nullptr: activation backward only
+  float* dy;
+  long long rows;
+  int C, stride, act;
+  float count;
+};
+hipError_t launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s);
+hipError_t launch_axpy(float alpha, const float* x, float* y, long long n, int accumulate, hipStream_t s);
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int n, int hw, int c, int stride, hipStream_t s);
+hipError_t launch_globalpool(const float* x, float* y, int n, int hw, int C, int xs, int ys, hipStream_t s);
+hipError_t launch_globalpool_bwd(const float* dy, float* dx, int n, int hw, int C, int xs, int ys, int accumulate,
+                                 hipStream_t s);
+hipError_t launch_mb_weight(const float* theta, const float* lws, float* W, float* colscale, int nin, int ncol, hipStream_t s);
+hipError_t launch_mb_weight_bwd(const float* theta, const float* colscale, const float* dW, float* dtheta, float* dlws,
+                                int nin, int ncol, int accumulate, hipStream_t s);
+hipError_t launch_mb_forward(const float* act_all, int nall, int as, int row0, int n, int nk, int nd, const float* bias,
+                             const float* feat, int fs, int fin, float* mb, int ms, hipStream_t s);
+hipError_t launch_mb_backward(const float* act_all, int nall, int as, int row0, int n, int nk, int nd, const float* df_all,
+                              int dfs, float* dact, int das, hipStream_t s);
+struct DiscHeadArgs {
+  float* p;       // [n][3]
+  float* loss;    // [n][4]: -log p[target0], -log p[target1], argmax==acc_target, 0
+  int target[2];  // -1 = unused
+  int acc_target;
+};
+hipError_t launch_disc_head(const float* mb, int ms, int nfeat, const float* Wd, int ncls, int n, const DiscHeadArgs& a,
+                            hipStream_t s);
+hipError_t launch_disc_head_bwd(const float* p, const float* Wd, int ncls, int nfeat, int n, int t0, float w0, int t1,
+                                float w1, float* dlogits, float* dmb, int ms, hipStream_t s);
+hipError_t launch_disc_head_wgrad(const float* mb, int ms, int nfeat, int n, const float* dlogits, int ncls, float* dWd,
+                                  int accumulate, hipStream_t s);
+hipError_t launch_sample(const float* mu, const float* ls, const float* eps, float* z0, float* klterm, int n, int d,
+                         int stride, int es, hipStream_t s);
+hipError_t launch_sample_bwd(const float* mu, const float* ls, const float* eps, const float* dz0, float* dmu, float* dls,
+                             int n, int d, int stride, int es, float klw, hipStream_t s);
+hipError_t launch_made_iaf_bwd(const float* z0, const float* dz, float* dz0, const float* wts, const float* bias, int n,
+                               int d, int zs, hipStream_t s);
+hipError_t launch_pair_loss(const float* a, const float* b, float* da, long long rows, int C, int stride, int mode,
+                            float w, int accumulate, float* partial, int nblocks, float scale, float* out, hipStream_t s);
+hipError_t launch_sum_rows(const float* x, int n, int width, float scale, float* out, hipStream_t s);
+hipError_t launch_ortho(const float* W, float* dW, int A, int B, int K, float c, float* vals, hipStream_t s);
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, long long n, float a_t, float b1, float b2, float eps,
+                       hipStream_t s);
+
 }  // namespace ian

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/ian.h"
+#include "../../include/ian_train.h"
 #include "ian_internal.h"
 
 using namespace ian;
@@ -244,12 +245,12 @@ void add_class(TgLayer& L, int py, int px, const std::vector<TgTap>& taps, long 
 
 // ----- weight repacking ------------------------------------------------------------------------------
 // CONV5S2 forward: IAN_simple.py:73-116. W (Cout,Cin,5,5); slab t=ky*5+kx: [CoutPad][CinPad] = W[co,ci,ky,kx]
-int pack_conv_fwd(ian_handle* h, OpPlan& op) {
+int pack_conv_fwd(ian_handle* h, OpPlan& op, bool allow_edge = true) {
   const int cin = op.d.cin, cout = op.d.cout, H = op.d.in_h, W = op.d.in_w;
   const HostTensor* Wt;
   int rc = need_param(h, op.name + ".W", {cout, cin, 5, 5}, &Wt);
   if (rc) return rc;
-  if (cin < 8) {  // edge kernel: [75][Cout], k=(c*5+ky)*5+kx
+  if (cin < 8 && allow_edge) {  // edge kernel: [75][Cout], k=(c*5+ky)*5+kx
     op.edge = true;
     op.h_edge_w.assign((size_t)75 * cout, 0.f);
     for (int co = 0; co < cout; ++co)
@@ -271,6 +272,39 @@ int pack_conv_fwd(ian_handle* h, OpPlan& op) {
   for (int co = 0; co < cout; ++co)
     for (int ci = 0; ci < cin; ++ci)
       for (int k = 0; k < 25; ++k) L.h_w[k * slab + (size_t)co * L.Cin + ci] = Wt->data[((size_t)co * cin + ci) * 25 + k];
+  return 0;
+}
+
+// CONV5S2 backward-data (training): dX[iy,ix,ci] = sum dY[oy,ox,co] * W[co,ci,ky,kx] with iy = 2*oy - 2 + ky.
+// Same parity-class decomposition as the transposed conv's forward (gather form, no atomics): class (py,px) =
+// parity of (iy,ix), taps ky = py, py+2, ..., oy = qy + (py + 2 - ky)/2.  Slabs [ci][co].
+int pack_conv_bwd(ian_handle* h, OpPlan& op) {
+  const int cin = op.d.cin, cout = op.d.cout, H = op.d.in_h, W = op.d.in_w;
+  const HostTensor* Wt;
+  int rc = need_param(h, op.name + ".W", {cout, cin, 5, 5}, &Wt);
+  if (rc) return rc;
+  TgLayer& L = op.bwd;
+  L.valid = true;
+  L.IH = H / 2; L.IW = W / 2; L.Cin = round_up(cout, 32); L.cin_real = cout;
+  L.QH = H / 2; L.QW = W / 2; L.si = 1; L.by = 0; L.bx = 0; L.so = 2; L.OH = H; L.OW = W;
+  L.Cout = cin; L.CoutPad = round_up(cin, 128);
+  const size_t slab = (size_t)L.CoutPad * L.Cin;
+  L.h_w.assign(slab * 25, 0.f);
+  size_t t_global = 0;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      std::vector<TgTap> taps;
+      const long long w_off = (long long)(t_global * slab);
+      for (int ky = py; ky < 5; ky += 2)
+        for (int kx = px; kx < 5; kx += 2) {
+          taps.push_back({(py + 2 - ky) / 2, (px + 2 - kx) / 2});
+          float* dst = L.h_w.data() + t_global * slab;
+          for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co) dst[(size_t)ci * L.Cin + co] = Wt->data[(((size_t)co * cin + ci) * 5 + ky) * 5 + kx];
+          ++t_global;
+        }
+      add_class(L, py, px, taps, w_off);
+    }
   return 0;
 }
 
@@ -339,6 +373,42 @@ int pack_deconv(ian_handle* h, OpPlan& op) {
       }
   }
   return 0;
+}
+
+// MDCL composite stencil (layers.py:207-258): tap list and, for every (3x3 branch, p, q), the tap it lands on.
+// Branch 0 = the base 3x3 (dilation 1), then one branch per scale > 0 in config order; scale 0 = the 1x1 mean
+// branch, which adds to the centre tap (tap 0).
+struct MdcTable {
+  std::vector<TgTap> taps;
+  std::vector<int> dil;                 // dilation of each 3x3 branch
+  std::vector<std::vector<int>> tapof;  // [branch][p*3+q] -> tap id
+  bool has_1x1 = false;
+};
+MdcTable mdc_table(const ian_op_desc& d) {
+  MdcTable T;
+  T.dil.push_back(1);
+  for (int i = 0; i < d.n_scales; ++i) {
+    if (d.scales[i] == 0) T.has_1x1 = true;
+    else T.dil.push_back(d.scales[i]);
+  }
+  std::map<std::pair<int, int>, int> index;
+  auto tap_id = [&](int dy, int dx) {
+    auto key = std::make_pair(dy, dx);
+    auto it = index.find(key);
+    if (it != index.end()) return it->second;
+    const int id = (int)T.taps.size();
+    index[key] = id;
+    T.taps.push_back({dy, dx});
+    return id;
+  };
+  tap_id(0, 0);
+  for (int dl : T.dil) {
+    std::vector<int> m(9);
+    for (int p = 0; p < 3; ++p)
+      for (int q = 0; q < 3; ++q) m[p * 3 + q] = tap_id(dl * (p - 1), dl * (q - 1));
+    T.tapof.push_back(m);
+  }
+  return T;
 }
 
 // MDC3: layers.py:207-258 collapsed into ONE composite sparse stencil (the idea sketched -- and broken --
@@ -1505,6 +1575,323 @@ void ian_destroy(ian_handle* h) {
     (void)hipEventDestroy(e.second);
   }
   delete h;
+}
+
+}  // extern "C"
+
+// ====================================== layer objects (include/ian_train.h) ==============================
+// One object per linear Lasagne layer of the training graph (train_IAN.py:116-149).  It reuses the inference
+// packers to learn WHERE every reference-layout weight lands in the forward / backward slabs (the packers are run
+// once on an index tensor), so that the per-step repacking after each optimiser update is a device-side gather.
+struct WgSchedule {
+  int cfg = 0, nitems = 0, nsplit = 1;
+  WgItem* d_items = nullptr;
+};
+
+struct ian_layer {
+  ian_handle ctx;  // options, split-K workspace, error text
+  OpPlan op;
+  bool is_mdc = false;
+  std::vector<int64_t> pnumel;
+  int* d_fwd_map = nullptr;
+  int* d_bwd_map = nullptr;
+  int* d_inv_map = nullptr;  // reference index -> forward slab index
+  size_t fwd_count = 0, bwd_count = 0;
+  MdcPackArgs mdc;
+  int mdc_param_branch[1 + IAN_MAX_SCALES];  // parameter i (>=1) -> branch id, or -1 for the 1x1 coefficient
+  float* d_partial = nullptr;
+  size_t partial_cap = 0;
+  float* d_dS = nullptr;  // MDC: reduced slab gradient
+  std::map<int, WgSchedule> wsched;
+};
+
+namespace {
+
+int lfail(ian_layer* l, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (l) l->ctx.err = buf;
+  return code;
+}
+
+#define LHIP(l, expr)                                                                                          \
+  do {                                                                                                         \
+    hipError_t _e = (expr);                                                                                    \
+    if (_e != hipSuccess) return lfail(l, -2, "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+  } while (0)
+
+// index tensor: value = reference index + 1 (exact in float32 below 2^24), 0 marks padding
+void add_index_param(ian_handle* h, const std::string& name, std::vector<int64_t> shape) {
+  HostTensor t;
+  t.shape = shape;
+  const int64_t n = t.numel();
+  t.data.resize(n);
+  for (int64_t i = 0; i < n; ++i) t.data[i] = (float)(i + 1);
+  h->params[name] = std::move(t);
+}
+
+std::vector<int> slab_to_map(const std::vector<float>& hw) {
+  std::vector<int> m(hw.size());
+  for (size_t i = 0; i < hw.size(); ++i) m[i] = (int)hw[i] - 1;
+  return m;
+}
+
+int build_wg_schedule(ian_layer* l, int nimg, WgSchedule** out) {
+  auto it = l->wsched.find(nimg);
+  if (it != l->wsched.end()) {
+    *out = &it->second;
+    return 0;
+  }
+  const TgLayer& L = l->op.fwd;
+  WgSchedule S;
+  const int M = nimg * L.QH * L.QW;
+  int bm, bn;
+  if (L.Cout <= 32) { S.cfg = WG_32x128; bm = 32; bn = 128; }
+  else if (L.Cin <= 32) { S.cfg = WG_128x32; bm = 128; bn = 32; }
+  else { S.cfg = WG_128x128; bm = 128; bn = 128; }
+  const int tiles_co = (std::min(L.CoutPad, round_up(L.Cout, bm)) + bm - 1) / bm;
+  const int tiles_ci = (L.Cin + bn - 1) / bn;
+  const int ntaps = (int)L.taps.size();
+  const long long base = (long long)ntaps * tiles_co * tiles_ci;
+  const int steps = (M + 31) / 32;
+  int nsplit = (int)std::max<long long>(1, (1024 + base - 1) / base);
+  nsplit = std::min(nsplit, std::max(1, steps / 4));  // at least 4 K-steps (128 pixels) per item
+  const int per = ((steps + nsplit - 1) / nsplit) * 32;
+  nsplit = (M + per - 1) / per;
+  S.nsplit = nsplit;
+  std::vector<WgItem> items;
+  for (int s = 0; s < nsplit; ++s)
+    for (int c = 0; c < (int)L.classes.size(); ++c)
+      for (int t = 0; t < L.classes[c].ntaps; ++t)
+        for (int a = 0; a < tiles_co; ++a)
+          for (int b = 0; b < tiles_ci; ++b) {
+            WgItem wi{c, L.classes[c].tap0 + t, a * bm, b * bn, s * per, std::min(M, (s + 1) * per), s, 0};
+            items.push_back(wi);
+          }
+  S.nitems = (int)items.size();
+  int rc = upload(&l->ctx, items, &S.d_items);
+  if (rc) return rc;
+  const size_t slab_total = (size_t)ntaps * L.CoutPad * L.Cin;
+  const size_t need = slab_total * nsplit;
+  if (need > l->partial_cap) {
+    if (l->d_partial) LHIP(l, hipFree(l->d_partial));
+    LHIP(l, hipMalloc((void**)&l->d_partial, need * sizeof(float)));
+    LHIP(l, hipMemset(l->d_partial, 0, need * sizeof(float)));
+    l->partial_cap = need;
+  }
+  it = l->wsched.emplace(nimg, S).first;
+  *out = &it->second;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ian_layer_last_error(ian_layer* l) { return l ? l->ctx.err.c_str() : "null layer"; }
+
+int ian_layer_create(const ian_op_desc* desc, int32_t deconv_flip, ian_layer** out) {
+  if (!desc || !out) return -1;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return -10;  // no HIP device: libian has no CPU fallback
+  }
+  std::unique_ptr<ian_layer> l(new ian_layer());
+  ian_handle* h = &l->ctx;
+  h->desc.deconv_flip = deconv_flip;
+  h->finalized = true;
+  OpPlan& op = l->op;
+  op.d = *desc;
+  op.name = "L";
+  op.d.name = nullptr;
+  op.d.bn_name = nullptr;
+  op.d.has_bias = 0;
+  const int cin = op.d.cin, cout = op.d.cout;
+  int rc = 0;
+  switch (op.d.kind) {
+    case IAN_OP_CONV5S2:
+      add_index_param(h, "L.W", {cout, cin, 5, 5});
+      if ((rc = pack_conv_fwd(h, op, false)) || (rc = pack_conv_bwd(h, op))) return rc;
+      l->pnumel = {(int64_t)cout * cin * 25};
+      break;
+    case IAN_OP_DECONV5S2:
+      if (cout <= 4) return -4;  // image-producing deconvs are not part of the trainable graph (IAN.py:139-181)
+      add_index_param(h, "L.W", {cin, cout, 5, 5});
+      if ((rc = pack_deconv(h, op))) return rc;
+      l->pnumel = {(int64_t)cout * cin * 25};
+      break;
+    case IAN_OP_DENSE: {
+      add_index_param(h, "L.W", {cin, cout});
+      std::vector<int> perm;
+      bool has = false;
+      if ((rc = pack_dense(h, op, perm, has))) return rc;
+      l->pnumel = {(int64_t)cout * cin};
+      break;
+    }
+    case IAN_OP_MDC3: {
+      if (op.d.n_scales < 0 || op.d.n_scales > IAN_MAX_SCALES) return -1;
+      // geometry / buffer sizes from the inference packer (values are overwritten by ian_layer_set_params)
+      HostTensor w; w.shape = {cout, cin, 3, 3}; w.data.assign((size_t)cout * cin * 9, 0.f);
+      h->params["LW"] = w;
+      HostTensor c; c.shape = {cout}; c.data.assign(cout, 0.f);
+      h->params["L_coeff_base"] = c;
+      for (int i = 0; i < op.d.n_scales; ++i)
+        h->params[op.d.scales[i] == 0 ? std::string("L_coeff_1x1") : "L_coeff_" + std::to_string(op.d.scales[i])] = c;
+      if ((rc = pack_mdc(h, op))) return rc;
+      l->is_mdc = true;
+      const MdcTable T = mdc_table(op.d);
+      if (T.taps.size() != op.fwd.taps.size() || T.taps.size() > 47) return -4;
+      MdcPackArgs& a = l->mdc;
+      memset(&a, 0, sizeof a);
+      a.ntaps = (int)T.taps.size(); a.cout = cout; a.cin = cin; a.nbranch = (int)T.dil.size();
+      a.f_rows = op.fwd.CoutPad; a.f_cols = op.fwd.Cin; a.b_rows = op.bwd.CoutPad; a.b_cols = op.bwd.Cin;
+      int e = 0;
+      for (int t = 0; t < a.ntaps; ++t) {
+        a.tap_start[t] = e;
+        for (int b = 0; b < a.nbranch; ++b)
+          for (int pq = 0; pq < 9; ++pq)
+            if (T.tapof[b][pq] == t) {
+              if (e >= 48) return -4;
+              a.ent_branch[e] = (unsigned char)b;
+              a.ent_pq[e] = (unsigned char)pq;
+              ++e;
+            }
+      }
+      a.tap_start[a.ntaps] = e;
+      l->pnumel = {(int64_t)cout * cin * 9, cout};
+      l->mdc_param_branch[0] = 0;
+      int nb = 1;
+      for (int i = 0; i < op.d.n_scales; ++i) {
+        l->pnumel.push_back(cout);
+        l->mdc_param_branch[1 + i] = (op.d.scales[i] == 0) ? -1 : nb++;
+      }
+      break;
+    }
+    default:
+      return -5;
+  }
+  if (!l->is_mdc) {
+    std::vector<int> fm = slab_to_map(op.fwd.h_w), bm;
+    if (op.bwd.valid) bm = slab_to_map(op.bwd.h_w);
+    std::vector<int> inv((size_t)l->pnumel[0], -1);
+    for (size_t i = 0; i < fm.size(); ++i)
+      if (fm[i] >= 0) inv[fm[i]] = (int)i;
+    l->fwd_count = fm.size();
+    l->bwd_count = bm.size();
+    if ((rc = upload(h, fm, &l->d_fwd_map)) || (rc = upload(h, bm, &l->d_bwd_map)) || (rc = upload(h, inv, &l->d_inv_map))) return rc;
+  }
+  if ((rc = upload_layer(h, op.fwd)) || (rc = upload_layer(h, op.bwd))) return rc;
+  if (l->is_mdc) {
+    l->mdc.slab_f = op.fwd.d_w;
+    l->mdc.slab_b = op.bwd.d_w;
+    if (hipMalloc((void**)&l->d_dS, op.fwd.w_floats * sizeof(float)) != hipSuccess) return -2;
+  }
+  h->params.clear();
+  *out = l.release();
+  return 0;
+}
+
+int32_t ian_layer_num_params(ian_layer* l) { return l ? (int32_t)l->pnumel.size() : -1; }
+int64_t ian_layer_param_numel(ian_layer* l, int32_t which) {
+  return (l && which >= 0 && which < (int)l->pnumel.size()) ? l->pnumel[which] : -1;
+}
+
+int ian_layer_set_params(ian_layer* l, const float* const* params, int32_t nparams, void* stream) {
+  if (!l || !params || nparams != (int)l->pnumel.size()) return lfail(l, -1, "ian_layer_set_params: expected %d parameter tensors", l ? (int)l->pnumel.size() : 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (!l->is_mdc) {
+    LHIP(l, launch_gather_pack(params[0], l->d_fwd_map, l->op.fwd.d_w, (long long)l->fwd_count, st));
+    if (l->op.bwd.valid) LHIP(l, launch_gather_pack(params[0], l->d_bwd_map, l->op.bwd.d_w, (long long)l->bwd_count, st));
+    return 0;
+  }
+  MdcPackArgs& a = l->mdc;
+  a.W = params[0];
+  a.coeff_1x1 = nullptr;
+  for (int i = 1; i < nparams; ++i) {
+    const int b = (i == 1) ? 0 : l->mdc_param_branch[i - 1];
+    if (i == 1) a.coeff[0] = params[1];
+    else if (b < 0) a.coeff_1x1 = params[i];
+    else a.coeff[b] = params[i];
+  }
+  LHIP(l, launch_mdc_pack(a, st));
+  return 0;
+}
+
+int ian_layer_forward(ian_layer* l, const float* x, int32_t n, float* y, int32_t y_stride, const float* bias,
+                      const float* res, int32_t act, void* stream) {
+  if (!l || !x || !y || n <= 0) return lfail(l, -1, "bad argument to ian_layer_forward");
+  TgEpilogue e;
+  e.scale = nullptr; e.shift = bias; e.res = res; e.yfwd = nullptr; e.act = act; e.scale_period = 0; e.mode = TG_EPI_FWD;
+  if (y_stride <= 0) y_stride = round_up(l->op.fwd.Cout, 32);
+  return run_tapgemm(&l->ctx, l->op.fwd, n, x, y, y_stride, e, (hipStream_t)stream);
+}
+
+int ian_layer_backward_data(ian_layer* l, const float* dy, int32_t n, float* dx, int32_t dx_stride, int32_t accumulate,
+                            void* stream) {
+  if (!l || !dy || !dx || n <= 0) return lfail(l, -1, "bad argument to ian_layer_backward_data");
+  if (!l->op.bwd.valid) return lfail(l, -9, "layer has no backward-data form");
+  TgEpilogue e;
+  e.scale = nullptr; e.shift = nullptr; e.res = accumulate ? dx : nullptr; e.yfwd = nullptr; e.act = IAN_ACT_NONE;
+  e.scale_period = 0; e.mode = TG_EPI_BWD;
+  if (dx_stride <= 0) dx_stride = round_up(l->op.bwd.Cout, 32);
+  return run_tapgemm(&l->ctx, l->op.bwd, n, dy, dx, dx_stride, e, (hipStream_t)stream);
+}
+
+int ian_layer_backward_weight(ian_layer* l, const float* x, const float* dy, int32_t n, float* const* dparams,
+                              int32_t nparams, int32_t accumulate, void* stream) {
+  if (!l || !x || !dy || !dparams || n <= 0 || nparams != (int)l->pnumel.size()) return lfail(l, -1, "bad argument to ian_layer_backward_weight");
+  hipStream_t st = (hipStream_t)stream;
+  const TgLayer& L = l->op.fwd;
+  WgSchedule* S;
+  int rc = build_wg_schedule(l, n, &S);
+  if (rc) return rc;
+  WgParams p;
+  p.x = x; p.dy = dy; p.partial = l->d_partial; p.items = S->d_items; p.classes = L.d_classes; p.taps = L.d_taps;
+  p.M = n * L.QH * L.QW; p.IH = L.IH; p.IW = L.IW; p.Cin = L.Cin;
+  p.qw_shift = ilog2_exact(L.QW); p.qhw_shift = ilog2_exact(L.QH * L.QW);
+  p.si = L.si; p.by = L.by; p.bx = L.bx; p.so = L.so; p.OH = L.OH; p.OW = L.OW;
+  p.dy_stride = (l->op.d.kind == IAN_OP_DENSE && l->op.d.unflat_c > 0) ? L.Cout : round_up(L.Cout, 32);
+  p.CoutPad = L.CoutPad; p.CinPad = L.Cin;
+  p.slab_total = (long long)L.taps.size() * L.CoutPad * L.Cin;
+  const size_t xb = (size_t)n * L.IH * L.IW * L.Cin * 4, yb = (size_t)n * L.OH * L.OW * p.dy_stride * 4;
+  if (xb > 0xFFFFFFF0ull || yb > 0xFFFFFFF0ull) return lfail(l, -7, "batch %d exceeds the 4 GiB buffer-descriptor range", n);
+  p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
+  LHIP(l, launch_tapwgrad(S->cfg, p, S->nitems, st));
+  if (!l->is_mdc) {
+    LHIP(l, launch_wgrad_reduce(l->d_partial, p.slab_total, S->nsplit, l->d_inv_map, dparams[0], l->pnumel[0], accumulate, st));
+    return 0;
+  }
+  LHIP(l, launch_wgrad_reduce(l->d_partial, p.slab_total, S->nsplit, nullptr, l->d_dS, p.slab_total, 0, st));
+  MdcCoeffGrads g;
+  memset(&g, 0, sizeof g);
+  g.d[0] = dparams[1];
+  for (int i = 2; i < nparams; ++i) {
+    const int b = l->mdc_param_branch[i - 1];
+    if (b < 0) g.d1x1 = dparams[i];
+    else g.d[b] = dparams[i];
+  }
+  LHIP(l, launch_mdc_unpack_grad(l->mdc, l->d_dS, dparams[0], g, accumulate, st));
+  return 0;
+}
+
+void ian_layer_destroy(ian_layer* l) {
+  if (!l) return;
+  for (TgLayer* L : {&l->op.fwd, &l->op.bwd}) {
+    free_schedules(*L);
+    if (L->d_w) (void)hipFree(L->d_w);
+    if (L->d_classes) (void)hipFree(L->d_classes);
+    if (L->d_taps) (void)hipFree(L->d_taps);
+  }
+  for (auto& kv : l->wsched)
+    if (kv.second.d_items) (void)hipFree(kv.second.d_items);
+  for (void* p : {(void*)l->d_fwd_map, (void*)l->d_bwd_map, (void*)l->d_inv_map, (void*)l->d_partial, (void*)l->d_dS,
+                  (void*)l->ctx.d_slab})
+    if (p) (void)hipFree(p);
+  delete l;
 }
 
 }  // extern "C"

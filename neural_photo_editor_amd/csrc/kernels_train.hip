@@ -1,0 +1,701 @@
+// Elementwise / reduction kernels of the train_IAN.py step (train_IAN.py:116-276): batch-statistics batch-norm
+// forward and backward (Lasagne batch_norm), activation backward, GlobalPool + MinibatchLayer
+// (layers.py:486-524) + the 3-way softmax discriminator head (IAN.py:209-216), Gaussian sampling / KL, MADE+IAF
+// backward-data, the pixel / feature losses, the orthogonal regulariser (train_IAN.py:158-165) and Adam
+// (lasagne.updates.adam, App. B.7).  All HBM-bound: float4 accesses on NHWC rows, two-stage fixed-order
+// reductions (no float atomics -> bitwise reproducible).
+#include <algorithm>
+
+#include "ian_internal.h"
+
+namespace ian {
+
+__device__ __forceinline__ float t_act(float v, int act) {
+  switch (act) {
+    case 1: return v > 0.f ? v : 0.f;
+    case 2: return v > 0.f ? v : 0.2f * v;
+    case 3: return v > 0.f ? v : expm1f(v);
+    case 4: return tanhf(v);
+    case 5: return 1.f / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+__device__ __forceinline__ float t_dact(float y, int act) {  // derivative through the OUTPUT y
+  switch (act) {
+    case 1: return y > 0.f ? 1.f : 0.f;
+    case 2: return y > 0.f ? 1.f : 0.2f;
+    case 3: return y > 0.f ? 1.f : y + 1.f;
+    case 4: return 1.f - y * y;
+    case 5: return y * (1.f - y);
+    default: return 1.f;
+  }
+}
+
+static inline int grid_for(long long total, int cap = 8192) {
+  long long b = (total + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-channel column statistics over NHWC rows.  partial[chunk][2][C]; then colstats_finalize -> sums[2][C]
+//   mode 0: s1 = sum x,  s2 = sum x^2                          (batch-norm forward statistics)
+//   mode 1: g = dA*act'(a): s1 = sum g, s2 = sum g*xhat, xhat = (y-mean)*inv_std   (batch-norm backward: dbeta, dgamma)
+//   mode 2: g = dA*act'(a): s1 = sum g                        (bias gradient)
+// block = 64 channel quads x 4 row lanes; grid = (row chunks, ceil(C/256))
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colstats_kernel(ColStatsArgs a) {
+  __shared__ float4 red[2][256];
+  const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 256 + q * 4;
+  const long long rows_per = (a.rows + gridDim.x - 1) / gridDim.x;
+  const long long r0 = (long long)blockIdx.x * rows_per, r1 = min(a.rows, r0 + rows_per);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (c < a.C) {
+    float4 mean = s1, istd = s1;
+    if (a.mode == 1) {
+      mean = *reinterpret_cast<const float4*>(a.mean + c);
+      istd = *reinterpret_cast<const float4*>(a.inv_std + c);
+    }
+    for (long long r = r0 + rl; r < r1; r += 4) {
+      const size_t off = (size_t)r * a.stride + c;
+      float4 x = *reinterpret_cast<const float4*>(a.x + off);
+      if (a.mode == 0) {
+        s1.x += x.x; s1.y += x.y; s1.z += x.z; s1.w += x.w;
+        s2.x += x.x * x.x; s2.y += x.y * x.y; s2.z += x.z * x.z; s2.w += x.w * x.w;
+      } else {
+        if (a.act) {
+          const float4 av = *reinterpret_cast<const float4*>(a.a + off);
+          x.x *= t_dact(av.x, a.act); x.y *= t_dact(av.y, a.act); x.z *= t_dact(av.z, a.act); x.w *= t_dact(av.w, a.act);
+        }
+        s1.x += x.x; s1.y += x.y; s1.z += x.z; s1.w += x.w;
+        if (a.mode == 1) {
+          const float4 y = *reinterpret_cast<const float4*>(a.y + off);
+          s2.x += x.x * (y.x - mean.x) * istd.x; s2.y += x.y * (y.y - mean.y) * istd.y;
+          s2.z += x.z * (y.z - mean.z) * istd.z; s2.w += x.w * (y.w - mean.w) * istd.w;
+        }
+      }
+    }
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (rl == 0 && c < a.C) {
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float4 u = red[0][q + 64 * k], v = red[1][q + 64 * k];
+      s1.x += u.x; s1.y += u.y; s1.z += u.z; s1.w += u.w;
+      s2.x += v.x; s2.y += v.y; s2.z += v.z; s2.w += v.w;
+    }
+    float* p = a.partial + (size_t)blockIdx.x * 2 * a.C;
+    *reinterpret_cast<float4*>(p + c) = s1;
+    *reinterpret_cast<float4*>(p + a.C + c) = s2;
+  }
+}
+__global__ __launch_bounds__(256) void colstats_finalize_kernel(const float* __restrict__ partial, int nchunks, int C,
+                                                                float* __restrict__ sums) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * C) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunks; ++k) s += partial[(size_t)k * 2 * C + i];
+  sums[i] = s;
+}
+hipError_t launch_colstats(const ColStatsArgs& a, int nchunks, float* sums, hipStream_t s) {
+  if (a.C & 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(colstats_kernel, dim3(nchunks, (a.C + 255) / 256), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(colstats_finalize_kernel, dim3((2 * a.C + 255) / 256), dim3(256), 0, s, a.partial, nchunks, a.C, sums);
+  return hipGetLastError();
+}
+
+// batch statistics -> folded affine (App. B.3): mean, biased variance, inv_std = 1/sqrt(var+eps)
+__global__ __launch_bounds__(256) void bn_make_affine_kernel(const float* __restrict__ sums, float count, float eps,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int C,
+                                                             float* __restrict__ mean, float* __restrict__ inv_std,
+                                                             float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float m = sums[c] / count;
+  float var = sums[C + c] / count - m * m;
+  var = var > 0.f ? var : 0.f;
+  const float is = 1.f / sqrtf(var + eps);
+  mean[c] = m;
+  inv_std[c] = is;
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - m * sc;
+}
+hipError_t launch_bn_make_affine(const float* sums, float count, float eps, const float* gamma, const float* beta,
+                                 int C, float* mean, float* inv_std, float* scale, float* shift, hipStream_t s) {
+  hipLaunchKernelGGL(bn_make_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, count, eps, gamma, beta, C, mean,
+                     inv_std, scale, shift);
+  return hipGetLastError();
+}
+
+// backward through [batch-norm ->] activation:   g = dA * act'(a)
+//   bn:   dy = scale * (g - s1/N - xhat * s2/N),  xhat = (y - mean) * inv_std,  (s1, s2) = sums from colstats mode 1
+//   else: dy = g
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+  const int c4n = a.C >> 2;
+  const long long total = a.rows * c4n;
+  const float invn = 1.f / a.count;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    const size_t off = (size_t)r * a.stride + c;
+    float4 g = *reinterpret_cast<const float4*>(a.dA + off);
+    if (a.act) {
+      const float4 av = *reinterpret_cast<const float4*>(a.a + off);
+      g.x *= t_dact(av.x, a.act); g.y *= t_dact(av.y, a.act); g.z *= t_dact(av.z, a.act); g.w *= t_dact(av.w, a.act);
+    }
+    if (a.sums) {
+      const float4 y = *reinterpret_cast<const float4*>(a.y + off);
+      const float4 mean = *reinterpret_cast<const float4*>(a.mean + c), istd = *reinterpret_cast<const float4*>(a.inv_std + c);
+      const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
+      const float4 s1 = *reinterpret_cast<const float4*>(a.sums + c), s2 = *reinterpret_cast<const float4*>(a.sums + a.C + c);
+      g.x = sc.x * (g.x - s1.x * invn - (y.x - mean.x) * istd.x * s2.x * invn);
+      g.y = sc.y * (g.y - s1.y * invn - (y.y - mean.y) * istd.y * s2.y * invn);
+      g.z = sc.z * (g.z - s1.z * invn - (y.z - mean.z) * istd.z * s2.z * invn);
+      g.w = sc.w * (g.w - s1.w * invn - (y.w - mean.w) * istd.w * s2.w * invn);
+    }
+    *reinterpret_cast<float4*>(a.dy + off) = g;
+  }
+}
+hipError_t launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s) {
+  if (a.C & 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(a.rows * (a.C >> 2))), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// y (+)= alpha * x on flat buffers (gradient accumulation, L2 regulariser gradient 2*reg*p)
+__global__ __launch_bounds__(256) void axpy_kernel(float alpha, const float* __restrict__ x, float* __restrict__ y,
+                                                   long long n, int accumulate) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    y[i] = (accumulate ? y[i] : 0.f) + alpha * x[i];
+}
+hipError_t launch_axpy(float alpha, const float* x, float* y, long long n, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, s, alpha, x, y, n, accumulate);
+  return hipGetLastError();
+}
+
+// NCHW [n,c,hw] -> NHWC with pixel stride `stride` (channels >= c left untouched = zero padding)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int n, int hw, int c, int stride) {
+  const long long total = (long long)n * hw * c;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    const long long pix = i / c;
+    const int p = (int)(pix % hw), b = (int)(pix / hw);
+    dst[pix * stride + ch] = src[((size_t)b * c + ch) * hw + p];
+  }
+}
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int n, int hw, int c, int stride, hipStream_t s) {
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)n * hw * c)), dim3(256), 0, s, src, dst, n, hw, c, stride);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// GlobalPoolLayer (mean over H*W) forward / backward on NHWC maps
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void globalpool_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
+                                                         int hw, int C, int xs, int ys) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n * C) return;
+  const int c = (int)(i % C), b = (int)(i / C);
+  float s = 0.f;
+  for (int p = 0; p < hw; ++p) s += x[((size_t)b * hw + p) * xs + c];
+  y[(size_t)b * ys + c] = s / hw;
+}
+__global__ __launch_bounds__(256) void globalpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                             int n, int hw, int C, int xs, int ys, int accumulate) {
+  const long long total = (long long)n * hw * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long long pix = i / C;
+    const int b = (int)(pix / hw);
+    const float g = dy[(size_t)b * ys + c] / hw;
+    float* o = dx + pix * xs + c;
+    *o = accumulate ? *o + g : g;
+  }
+}
+hipError_t launch_globalpool(const float* x, float* y, int n, int hw, int C, int xs, int ys, hipStream_t s) {
+  hipLaunchKernelGGL(globalpool_kernel, dim3(grid_for((long long)n * C, 1 << 20)), dim3(256), 0, s, x, y, n, hw, C, xs, ys);
+  return hipGetLastError();
+}
+hipError_t launch_globalpool_bwd(const float* dy, float* dx, int n, int hw, int C, int xs, int ys, int accumulate,
+                                 hipStream_t s) {
+  hipLaunchKernelGGL(globalpool_bwd_kernel, dim3(grid_for((long long)n * hw * C)), dim3(256), 0, s, dy, dx, n, hw, C, xs, ys,
+                     accumulate);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// MinibatchLayer (layers.py:486-524)
+// ------------------------------------------------------------------------------------------------
+// W = theta * (exp(log_weight_scale) / sqrt(sum_i theta^2))  (layers.py:494): one thread per column (k,d)
+__global__ __launch_bounds__(256) void mb_weight_kernel(const float* __restrict__ theta, const float* __restrict__ lws,
+                                                        float* __restrict__ W, float* __restrict__ colscale, int nin,
+                                                        int ncol) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= ncol) return;
+  float ss = 0.f;
+  for (int i = 0; i < nin; ++i) {
+    const float t = theta[(size_t)i * ncol + j];
+    ss += t * t;
+  }
+  const float sc = expf(lws[j]) / sqrtf(ss);
+  colscale[j] = sc;
+  for (int i = 0; i < nin; ++i) W[(size_t)i * ncol + j] = theta[(size_t)i * ncol + j] * sc;
+}
+// dtheta[i,j] = dW[i,j]*s_j - theta[i,j]*s_j*(sum_i' dW[i',j]*theta[i',j]) / sum_i' theta[i',j]^2 ; dlws[j] = sum_i dW[i,j]*W[i,j]
+__global__ __launch_bounds__(256) void mb_weight_bwd_kernel(const float* __restrict__ theta,
+                                                            const float* __restrict__ colscale,
+                                                            const float* __restrict__ dW, float* __restrict__ dtheta,
+                                                            float* __restrict__ dlws, int nin, int ncol, int accumulate) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= ncol) return;
+  float ss = 0.f, dot = 0.f;
+  for (int i = 0; i < nin; ++i) {
+    const float t = theta[(size_t)i * ncol + j];
+    ss += t * t;
+    dot += dW[(size_t)i * ncol + j] * t;
+  }
+  const float sc = colscale[j];
+  for (int i = 0; i < nin; ++i) {
+    const size_t o = (size_t)i * ncol + j;
+    const float g = dW[o] * sc - theta[o] * sc * dot / ss;
+    dtheta[o] = accumulate ? dtheta[o] + g : g;
+  }
+  const float gl = dot * sc;
+  dlws[j] = accumulate ? dlws[j] + gl : gl;
+}
+hipError_t launch_mb_weight(const float* theta, const float* lws, float* W, float* colscale, int nin, int ncol, hipStream_t s) {
+  hipLaunchKernelGGL(mb_weight_kernel, dim3((ncol + 255) / 256), dim3(256), 0, s, theta, lws, W, colscale, nin, ncol);
+  return hipGetLastError();
+}
+hipError_t launch_mb_weight_bwd(const float* theta, const float* colscale, const float* dW, float* dtheta, float* dlws,
+                                int nin, int ncol, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(mb_weight_bwd_kernel, dim3((ncol + 255) / 256), dim3(256), 0, s, theta, colscale, dW, dtheta, dlws, nin,
+                     ncol, accumulate);
+  return hipGetLastError();
+}
+
+// f[b,k] = sum_b' exp(-(sum_d |act[b,k,d]-act[b',k,d]| + 1e6*[b==b'])) + bias[k]   (layers.py:507-520)
+// act_all holds the activations of the WHOLE minibatch (all ranks, nall rows of stride as); this rank owns rows
+// [row0, row0+n).  out: mb[b, fin + k] (the first fin columns are the input features, copied here: layers.py:524).
+__global__ __launch_bounds__(256) void mb_forward_kernel(const float* __restrict__ act_all, int nall, int as, int row0,
+                                                         int n, int nk, int nd, const float* __restrict__ bias,
+                                                         const float* __restrict__ feat, int fs, int fin,
+                                                         float* __restrict__ mb, int ms) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < (long long)n * fin) {
+    const int b = (int)(i / fin), c = (int)(i % fin);
+    mb[(size_t)b * ms + c] = feat[(size_t)b * fs + c];
+  }
+  if (i >= (long long)n * nk) return;
+  const int k = (int)(i % nk), b = (int)(i / nk);
+  const float* me = act_all + (size_t)(row0 + b) * as + k * nd;
+  float f = 0.f;
+  for (int o = 0; o < nall; ++o) {
+    const float* ot = act_all + (size_t)o * as + k * nd;
+    float a = (o == row0 + b) ? 1e6f : 0.f;
+    for (int d = 0; d < nd; ++d) a += fabsf(me[d] - ot[d]);
+    f += expf(-a);
+  }
+  mb[(size_t)b * ms + fin + k] = f + bias[k];
+}
+// dact[b,k,d] = - sum_b' exp(-A[b,k,b']) * (df[b,k] + df[b',k]) * sign(act[b,k,d]-act[b',k,d]);  df_all: all ranks' df (stride dfs)
+__global__ __launch_bounds__(256) void mb_backward_kernel(const float* __restrict__ act_all, int nall, int as, int row0,
+                                                          int n, int nk, int nd, const float* __restrict__ df_all,
+                                                          int dfs, float* __restrict__ dact, int das) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n * nk) return;
+  const int k = (int)(i % nk), b = (int)(i / nk);
+  const float* me = act_all + (size_t)(row0 + b) * as + k * nd;
+  const float dfb = df_all[(size_t)(row0 + b) * dfs + k];
+  float g[8];
+  for (int d = 0; d < nd; ++d) g[d] = 0.f;
+  for (int o = 0; o < nall; ++o) {
+    if (o == row0 + b) continue;
+    const float* ot = act_all + (size_t)o * as + k * nd;
+    float a = 0.f;
+    for (int d = 0; d < nd; ++d) a += fabsf(me[d] - ot[d]);
+    const float w = expf(-a) * (dfb + df_all[(size_t)o * dfs + k]);
+    for (int d = 0; d < nd; ++d) {
+      const float df = me[d] - ot[d];
+      g[d] -= w * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+    }
+  }
+  for (int d = 0; d < nd; ++d) dact[(size_t)b * das + k * nd + d] = g[d];
+}
+hipError_t launch_mb_forward(const float* act_all, int nall, int as, int row0, int n, int nk, int nd, const float* bias,
+                             const float* feat, int fs, int fin, float* mb, int ms, hipStream_t s) {
+  const long long total = std::max<long long>((long long)n * nk, (long long)n * fin);
+  hipLaunchKernelGGL(mb_forward_kernel, dim3(grid_for(total, 1 << 20)), dim3(256), 0, s, act_all, nall, as, row0, n, nk, nd, bias,
+                     feat, fs, fin, mb, ms);
+  return hipGetLastError();
+}
+hipError_t launch_mb_backward(const float* act_all, int nall, int as, int row0, int n, int nk, int nd, const float* df_all,
+                              int dfs, float* dact, int das, hipStream_t s) {
+  if (nd > 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(mb_backward_kernel, dim3(grid_for((long long)n * nk, 1 << 20)), dim3(256), 0, s, act_all, nall, as, row0, n,
+                     nk, nd, df_all, dfs, dact, das);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// discriminator head: logits = mb @ Wd (1524 x 3, no bias), softmax, categorical cross-entropy (IAN.py:210-216,
+// train_IAN.py:228-250).  One block (256 threads) per sample.
+//   out per sample: p[3]; loss terms -log p[target_t] for up to 2 targets; correct = (argmax p == acc_target)
+//   dlogits = sum_t w_t * (p - onehot(target_t))          (w_t already holds loss weight / global batch)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void disc_head_kernel(const float* __restrict__ mb, int ms, int nfeat,
+                                                        const float* __restrict__ Wd, int ncls, DiscHeadArgs a) {
+  __shared__ float red[3][256];
+  const int b = blockIdx.x;
+  float l[3] = {0.f, 0.f, 0.f};
+  for (int j = threadIdx.x; j < nfeat; j += 256) {
+    const float v = mb[(size_t)b * ms + j];
+    for (int k = 0; k < 3; ++k) l[k] += v * Wd[(size_t)j * ncls + k];
+  }
+  for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = l[k];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float z0 = red[0][0], z1 = red[1][0], z2 = red[2][0];
+    const float m = fmaxf(z0, fmaxf(z1, z2));
+    const float e0 = expf(z0 - m), e1 = expf(z1 - m), e2 = expf(z2 - m);
+    const float inv = 1.f / (e0 + e1 + e2);
+    const float p[3] = {e0 * inv, e1 * inv, e2 * inv};
+    for (int k = 0; k < 3; ++k) a.p[(size_t)b * 3 + k] = p[k];
+    int am = 0;
+    if (p[1] > p[am]) am = 1;
+    if (p[2] > p[am]) am = 2;
+    for (int t = 0; t < 2; ++t) a.loss[(size_t)b * 4 + t] = (a.target[t] >= 0) ? -logf(p[a.target[t]]) : 0.f;
+    a.loss[(size_t)b * 4 + 2] = (am == a.acc_target) ? 1.f : 0.f;
+    a.loss[(size_t)b * 4 + 3] = 0.f;
+  }
+}
+// dlogits[b,k] = sum_t w[t]*(p[b,k] - [k==target[t]]);  dmb[b,j] = sum_k dlogits[b,k]*Wd[j,k]
+__global__ __launch_bounds__(256) void disc_head_bwd_kernel(const float* __restrict__ p, const float* __restrict__ Wd,
+                                                            int ncls, int nfeat, int t0, float w0, int t1, float w1,
+                                                            float* __restrict__ dlogits, float* __restrict__ dmb, int ms) {
+  const int b = blockIdx.x;
+  float dl[3];
+  for (int k = 0; k < 3; ++k) {
+    const float pk = p[(size_t)b * 3 + k];
+    dl[k] = (t0 >= 0 ? w0 * (pk - (k == t0 ? 1.f : 0.f)) : 0.f) + (t1 >= 0 ? w1 * (pk - (k == t1 ? 1.f : 0.f)) : 0.f);
+  }
+  if (threadIdx.x < 3) dlogits[(size_t)b * 4 + threadIdx.x] = dl[threadIdx.x];
+  for (int j = threadIdx.x; j < nfeat; j += 256) {
+    float g = 0.f;
+    for (int k = 0; k < 3; ++k) g += dl[k] * Wd[(size_t)j * ncls + k];
+    dmb[(size_t)b * ms + j] = g;
+  }
+}
+// dWd[j,k] (+)= sum_b mb[b,j]*dlogits[b,k]   (one thread per (j,k), fixed order over b)
+__global__ __launch_bounds__(256) void disc_head_wgrad_kernel(const float* __restrict__ mb, int ms, int nfeat, int n,
+                                                              const float* __restrict__ dlogits, int ncls,
+                                                              float* __restrict__ dWd, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nfeat * ncls) return;
+  const int j = i / ncls, k = i % ncls;
+  float s = 0.f;
+  for (int b = 0; b < n; ++b) s += mb[(size_t)b * ms + j] * dlogits[(size_t)b * 4 + k];
+  dWd[i] = accumulate ? dWd[i] + s : s;
+}
+hipError_t launch_disc_head(const float* mb, int ms, int nfeat, const float* Wd, int ncls, int n, const DiscHeadArgs& a,
+                            hipStream_t s) {
+  if (ncls != 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(disc_head_kernel, dim3(n), dim3(256), 0, s, mb, ms, nfeat, Wd, ncls, a);
+  return hipGetLastError();
+}
+hipError_t launch_disc_head_bwd(const float* p, const float* Wd, int ncls, int nfeat, int n, int t0, float w0, int t1,
+                                float w1, float* dlogits, float* dmb, int ms, hipStream_t s) {
+  hipLaunchKernelGGL(disc_head_bwd_kernel, dim3(n), dim3(256), 0, s, p, Wd, ncls, nfeat, t0, w0, t1, w1, dlogits, dmb, ms);
+  return hipGetLastError();
+}
+hipError_t launch_disc_head_wgrad(const float* mb, int ms, int nfeat, int n, const float* dlogits, int ncls, float* dWd,
+                                  int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(disc_head_wgrad_kernel, dim3((nfeat * ncls + 255) / 256), dim3(256), 0, s, mb, ms, nfeat, n, dlogits, ncls,
+                     dWd, accumulate);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// latent: GaussianSampleLayer (layers.py:419-433) + KL (train_IAN.py:172), forward and backward
+// ------------------------------------------------------------------------------------------------
+// z0 = mu + exp(ls)*eps ; klterm[b,j] = 1 + 2 ls - mu^2 - exp(2 ls)   (summed later)
+__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ mu, const float* __restrict__ ls,
+                                                     const float* __restrict__ eps, float* __restrict__ z0,
+                                                     float* __restrict__ klterm, int n, int d, int stride, int es) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * d) return;
+  const int b = i / d, j = i % d;
+  const size_t o = (size_t)b * stride + j;
+  const float m = mu[o], l = ls[o];
+  z0[o] = m + expf(l) * eps[(size_t)b * es + j];
+  klterm[i] = 1.f + 2.f * l - m * m - expf(2.f * l);
+}
+// dmu = dz0 + klw*mu ; dls = dz0*exp(ls)*eps + klw*(exp(2 ls) - 1)      klw = kl_weight / (B_global * d)
+__global__ __launch_bounds__(256) void sample_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ ls,
+                                                         const float* __restrict__ eps, const float* __restrict__ dz0,
+                                                         float* __restrict__ dmu, float* __restrict__ dls, int n, int d,
+                                                         int stride, int es, float klw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * d) return;
+  const int b = i / d, j = i % d;
+  const size_t o = (size_t)b * stride + j;
+  const float m = mu[o], l = ls[o], g = dz0[o];
+  dmu[o] = g + klw * m;
+  dls[o] = g * expf(l) * eps[(size_t)b * es + j] + klw * (expf(2.f * l) - 1.f);
+}
+hipError_t launch_sample(const float* mu, const float* ls, const float* eps, float* z0, float* klterm, int n, int d,
+                         int stride, int es, hipStream_t s) {
+  hipLaunchKernelGGL(sample_kernel, dim3((n * d + 255) / 256), dim3(256), 0, s, mu, ls, eps, z0, klterm, n, d, stride, es);
+  return hipGetLastError();
+}
+hipError_t launch_sample_bwd(const float* mu, const float* ls, const float* eps, const float* dz0, float* dmu, float* dls,
+                             int n, int d, int stride, int es, float klw, hipStream_t s) {
+  hipLaunchKernelGGL(sample_bwd_kernel, dim3((n * d + 255) / 256), dim3(256), 0, s, mu, ls, eps, dz0, dmu, dls, n, d, stride, es,
+                     klw);
+  return hipGetLastError();
+}
+
+// MADE x2 + IAF backward-data (layers.py:641-650, 735-853): z = (z0 - m(z0)) / exp(s(z0)); the MADE parameters are
+// never trained (train_IAN.py:184-194), only dL/dz0 is needed.  wts/bias as in made_iaf_kernel (pre-masked).
+//   u = dz / exp(s);  dz0 = u + Jm^T(-u) + Js^T(-dz*z)
+__global__ __launch_bounds__(128) void made_iaf_bwd_kernel(const float* __restrict__ z0, const float* __restrict__ dz,
+                                                           float* __restrict__ dz0, const float* __restrict__ wts,
+                                                           const float* __restrict__ bias, int d, int zs) {
+  __shared__ float zin[128], hm[128], hl[128], vm[128], vl[128], dhm[128], dhl[128];
+  const int t = threadIdx.x, row = blockIdx.x;
+  const int dd = d * d;
+  zin[t] = (t < d) ? z0[(size_t)row * zs + t] : 0.f;
+  __syncthreads();
+  float am = 0.f, al = 0.f;
+  if (t < d) {
+    am = bias[0 * d + t];
+    al = bias[3 * d + t];
+    for (int i = 0; i < d; ++i) {
+      am = fmaf(zin[i], wts[0 * dd + i * d + t], am);
+      al = fmaf(zin[i], wts[3 * dd + i * d + t], al);
+    }
+  }
+  hm[t] = am > 0.f ? am : 0.f;
+  hl[t] = al > 0.f ? al : 0.f;
+  __syncthreads();
+  float u = 0.f;
+  if (t < d) {
+    float om = bias[1 * d + t], dm = bias[2 * d + t], ol = bias[4 * d + t], dl = bias[5 * d + t];
+    for (int i = 0; i < d; ++i) {
+      om = fmaf(hm[i], wts[1 * dd + i * d + t], om);
+      dm = fmaf(zin[i], wts[2 * dd + i * d + t], dm);
+      ol = fmaf(hl[i], wts[4 * dd + i * d + t], ol);
+      dl = fmaf(zin[i], wts[5 * dd + i * d + t], dl);
+    }
+    const float mu = om + dm, ls = ol + dl;
+    const float z = (zin[t] - mu) / expf(ls);
+    const float g = dz[(size_t)row * zs + t];
+    u = g / expf(ls);
+    vm[t] = -u;       // dL/d(mu output)
+    vl[t] = -g * z;   // dL/d(ls output)
+  } else {
+    vm[t] = 0.f;
+    vl[t] = 0.f;
+  }
+  __syncthreads();
+  // hidden gradients: dh[i] = (sum_j v[j]*W1[i][j]) * (h[i] > 0)
+  float gm = 0.f, gl = 0.f;
+  if (t < d) {
+    for (int j = 0; j < d; ++j) {
+      gm = fmaf(vm[j], wts[1 * dd + t * d + j], gm);
+      gl = fmaf(vl[j], wts[4 * dd + t * d + j], gl);
+    }
+  }
+  dhm[t] = (hm[t] > 0.f) ? gm : 0.f;
+  dhl[t] = (hl[t] > 0.f) ? gl : 0.f;
+  __syncthreads();
+  if (t < d) {
+    float g = u;
+    for (int j = 0; j < d; ++j) {
+      g = fmaf(dhm[j], wts[0 * dd + t * d + j], g);
+      g = fmaf(vm[j], wts[2 * dd + t * d + j], g);
+      g = fmaf(dhl[j], wts[3 * dd + t * d + j], g);
+      g = fmaf(vl[j], wts[5 * dd + t * d + j], g);
+    }
+    dz0[(size_t)row * zs + t] = g;
+  }
+}
+hipError_t launch_made_iaf_bwd(const float* z0, const float* dz, float* dz0, const float* wts, const float* bias, int n,
+                               int d, int zs, hipStream_t s) {
+  if (d > 128) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(made_iaf_bwd_kernel, dim3(n), dim3(128), 0, s, z0, dz, dz0, wts, bias, d, zs);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// losses between two tensors (train_IAN.py:169,244,279).  Strided views: element (r, c) at r*stride + c, c < C.
+//   mode 0 (pixel_loss):  v1 = 2*|a - b + 1e-8|,  v2 = (a-b)^2 ;  da (+)= w * 2*sign(a - b + 1e-8)
+//   mode 1 (feature MSE): v1 = (a-b)^2          ;  da (+)= w * 2*(a-b)   (b is constant)
+// partial[block][2] then sum_finalize.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ da, long long rows, int C, int stride,
+                                                        int mode, float w, int accumulate, float* __restrict__ partial) {
+  __shared__ float red[2][256];
+  const long long total = rows * C;
+  float s1 = 0.f, s2 = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / C;
+    const int c = (int)(i % C);
+    const size_t o = (size_t)r * stride + c;
+    const float d = a[o] - b[o];
+    float g;
+    if (mode == 0) {
+      const float e = d + 1e-8f;
+      s1 += 2.f * fabsf(e);
+      s2 += d * d;
+      g = 2.f * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+    } else {
+      s1 += d * d;
+      g = 2.f * d;
+    }
+    if (da) da[o] = (accumulate ? da[o] : 0.f) + w * g;
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[(size_t)blockIdx.x * 2] = red[0][0];
+    partial[(size_t)blockIdx.x * 2 + 1] = red[1][0];
+  }
+}
+// out[q] = scale * sum_k partial[k*width + q]   for q < width   (single block, fixed order)
+__global__ __launch_bounds__(64) void sum_finalize_kernel(const float* __restrict__ partial, int n, int width, float scale,
+                                                          float* __restrict__ out) {
+  const int q = threadIdx.x;
+  if (q >= width) return;
+  float s = 0.f;
+  for (int k = 0; k < n; ++k) s += partial[(size_t)k * width + q];
+  out[q] = s * scale;
+}
+hipError_t launch_pair_loss(const float* a, const float* b, float* da, long long rows, int C, int stride, int mode,
+                            float w, int accumulate, float* partial, int nblocks, float scale, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(pair_loss_kernel, dim3(nblocks), dim3(256), 0, s, a, b, da, rows, C, stride, mode, w, accumulate, partial);
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nblocks, 2, scale, out);
+  return hipGetLastError();
+}
+// column sums of a small [n][width] array (per-sample loss terms, KL terms): out[q] = scale * sum_r x[r*width+q]
+hipError_t launch_sum_rows(const float* x, int n, int width, float scale, float* out, hipStream_t s) {
+  if (width > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(64), 0, s, x, n, width, scale, out);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// orthogonal regulariser (train_IAN.py:158-165) on a 4-D W (A,B,K,K) in reference layout:
+//   y[a,i,j] = sum_{b,k} W[a,b,i,k]*W[a,b,j,k] - [i==j];   value = sum |y|;   dW[a,b,i,k] += c * 2*sum_j sign(y[a,i,j])*W[a,b,j,k]
+// one block per a.  value partial per block -> vals[a].
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void ortho_kernel(const float* __restrict__ W, float* __restrict__ dW, int B, float c,
+                                                    float* __restrict__ vals) {
+  __shared__ float red[256];
+  __shared__ float y[K * K];
+  const int a = blockIdx.x;
+  const float* Wa = W + (size_t)a * B * K * K;
+  float part[K * K];
+#pragma unroll
+  for (int e = 0; e < K * K; ++e) part[e] = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float w[K * K];
+#pragma unroll
+    for (int e = 0; e < K * K; ++e) w[e] = Wa[(size_t)b * K * K + e];
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) s += w[i * K + k] * w[j * K + k];
+        part[i * K + j] += s;
+      }
+  }
+  for (int e = 0; e < K * K; ++e) {
+    red[threadIdx.x] = part[e];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) y[e] = red[0] - ((e / K == e % K) ? 1.f : 0.f);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float v = 0.f;
+    for (int e = 0; e < K * K; ++e) v += fabsf(y[e]);
+    vals[a] = v;
+  }
+  if (!dW) return;
+  float* dWa = dW + (size_t)a * B * K * K;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float w[K * K];
+#pragma unroll
+    for (int e = 0; e < K * K; ++e) w[e] = Wa[(size_t)b * K * K + e];
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float g = 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const float yy = y[i * K + j];
+          g += (yy > 0.f ? 1.f : (yy < 0.f ? -1.f : 0.f)) * w[j * K + k];
+        }
+        dWa[(size_t)b * K * K + i * K + k] += 2.f * c * g;
+      }
+  }
+}
+hipError_t launch_ortho(const float* W, float* dW, int A, int B, int K, float c, float* vals, hipStream_t s) {
+  if (K == 5) hipLaunchKernelGGL(ortho_kernel<5>, dim3(A), dim3(256), 0, s, W, dW, B, c, vals);
+  else if (K == 3) hipLaunchKernelGGL(ortho_kernel<3>, dim3(A), dim3(256), 0, s, W, dW, B, c, vals);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// lasagne.updates.adam (App. B.7) on a flat parameter group:
+//   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g^2 ; p -= a_t * m / (sqrt(v) + eps),   a_t = lr*sqrt(1-b2^t)/(1-b1^t)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n, float a_t,
+                                                   float b1, float b2, float eps) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= a_t * mi / (sqrtf(vi) + eps);
+  }
+}
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, long long n, float a_t, float b1, float b2, float eps,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, n, a_t, b1, b2, eps);
+  return hipGetLastError();
+}
+
+}  // namespace ian

@@ -1,0 +1,301 @@
+// tapwgrad: backward-weight of every tap-GEMM layer (5x5/s2 conv, 5x5/s2 transposed conv, composite MDC stencil,
+// dense) for the train_IAN.py step (train_IAN.py:253-273: T.grad wrt the conv / deconv / dense / MDCL weights,
+// which Theano lowers to cuDNN GpuDnnConvGradW / GEMM calls).
+//
+//   dS[t][co][ci] = sum_m dY[out_pixel(m)][co] * X[in_pixel(m) + d_t][ci]        (fwd slab layout [tap][CoutPad][CinPad])
+//
+// Same geometry tables (classes, taps) as the forward tapgemm; here the pixel index m is the CONTRACTION index:
+//   * both operands are read exactly as they lie in HBM (NHWC rows, channels contiguous): 16 B/lane coalesced
+//     buffer loads, halo / ragged rows / channel-tile overhang masked by an out-of-range offset (hardware zero fill);
+//   * LDS tiles are [m][channel]; an MFMA operand fragment is 32 consecutive channels of one m row -> 32 consecutive
+//     floats per half-wave: conflict-free ds_read_b32, no transposition anywhere;
+//   * v_mfma_f32_32x32x2_f32 (exact fp32), two m rows per instruction, accumulators in registers over the item's
+//     whole m range; the host splits m so that taps x channel tiles x splits fills the chip; each split writes a
+//     partial slab, summed (and scattered to the reference parameter layout) by wgrad_reduce_kernel in a fixed order
+//     -> bitwise reproducible gradients.
+#include "ian_internal.h"
+
+namespace ian {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 wg_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+  float4 r;
+  r.x = __uint_as_float(v.x);
+  r.y = __uint_as_float(v.y);
+  r.z = __uint_as_float(v.z);
+  r.w = __uint_as_float(v.w);
+  return r;
+}
+
+constexpr int WG_BK = 32;  // m rows per K-step
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void tapwgrad_kernel(const WgParams p) {
+  constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
+  constexpr int A_TPR = BM / 4, B_TPR = BN / 4;          // threads per tile row (float4 each)
+  constexpr int A_RPP = 256 / A_TPR, B_RPP = 256 / B_TPR;  // rows per pass
+  constexpr int A_CH = (WG_BK + A_RPP - 1) / A_RPP, B_CH = (WG_BK + B_RPP - 1) / B_RPP;
+  static_assert(WM * WN == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                      // [2][32][BM]
+  float* Bs = smem + 2 * WG_BK * BM;     // [2][32][BN]
+
+  const WgItem it = p.items[blockIdx.x];
+  if (it.m0 >= it.m1) return;
+  const TgClass cl = p.classes[it.cls];
+  const TgTap tp = p.taps[it.tap];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+
+  const int a_c = (tid % A_TPR) * 4, a_r = tid / A_TPR;
+  const int b_c = (tid % B_TPR) * 4, b_r = tid / B_TPR;
+  const bool a_col_ok = (it.co0 + a_c) < p.dy_stride;  // channel-tile overhang reads as zero
+  const bool b_col_ok = (it.ci0 + b_c) < p.Cin;
+  const int qhw_mask = (1 << p.qhw_shift) - 1, qw_mask = (1 << p.qw_shift) - 1;
+
+  float4 ra[A_CH], rb[B_CH];
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto load_tiles = [&](int mbase) {
+#pragma unroll
+    for (int j = 0; j < A_CH; ++j) {
+      const int row = a_r + j * A_RPP;
+      const int m = mbase + row;
+      const int n = m >> p.qhw_shift, rem = m & qhw_mask;
+      const int oy = (rem >> p.qw_shift) * p.so + cl.py, ox = (rem & qw_mask) * p.so + cl.px;
+      const bool ok = a_col_ok && (row < WG_BK) && (m < it.m1);
+      const unsigned off = (unsigned)((((n * p.OH + oy) * p.OW + ox) * p.dy_stride + it.co0 + a_c) * 4);
+      ra[j] = wg_load4(yrsrc, ok ? off : 0xFFFFFFF0u);
+    }
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) {
+      const int row = b_r + j * B_RPP;
+      const int m = mbase + row;
+      const int n = m >> p.qhw_shift, rem = m & qhw_mask;
+      const int iy = (rem >> p.qw_shift) * p.si + p.by + tp.dy, ix = (rem & qw_mask) * p.si + p.bx + tp.dx;
+      const bool ok = b_col_ok && (row < WG_BK) && (m < it.m1) && ((unsigned)iy < (unsigned)p.IH) && ((unsigned)ix < (unsigned)p.IW);
+      const unsigned off = (unsigned)((((n * p.IH + iy) * p.IW + ix) * p.Cin + it.ci0 + b_c) * 4);
+      rb[j] = wg_load4(xrsrc, ok ? off : 0xFFFFFFF0u);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < A_CH; ++j) {
+      const int row = a_r + j * A_RPP;
+      if (row < WG_BK) *reinterpret_cast<float4*>(As + (buf * WG_BK + row) * BM + a_c) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) {
+      const int row = b_r + j * B_RPP;
+      if (row < WG_BK) *reinterpret_cast<float4*>(Bs + (buf * WG_BK + row) * BN + b_c) = rb[j];
+    }
+  };
+
+  const int half = lane >> 5, l31 = lane & 31;
+  const float* a_base = As + half * BM + wm * (BM / WM) + l31;
+  const float* b_base = Bs + half * BN + wn * (BN / WN) + l31;
+  auto compute = [&](int buf) {
+    const float* a_s = a_base + buf * WG_BK * BM;
+    const float* b_s = b_base + buf * WG_BK * BN;
+#pragma unroll
+    for (int kk = 0; kk < WG_BK / 2; ++kk) {
+      float av[FM], bv[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) av[i] = a_s[kk * 2 * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bv[j] = b_s[kk * 2 * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  load_tiles(it.m0);
+  store_tiles(0);
+  __syncthreads();
+  int cur = 0;
+  for (int mb = it.m0 + WG_BK; mb < it.m1; mb += WG_BK) {
+    load_tiles(mb);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(cur);
+    store_tiles(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  compute(cur);
+
+  // partial[split][tap][co][ci]; C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* out = p.partial + (size_t)it.split * p.slab_total + (size_t)it.tap * p.CoutPad * p.CinPad;
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = it.co0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co >= p.CoutPad) continue;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int ci = it.ci0 + wn * (BN / WN) + j * 32 + l31;
+        if (ci < p.CinPad) out[(size_t)co * p.CinPad + ci] = acc[i][j][r];
+      }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_wg(const WgParams& p, int nitems, hipStream_t s) {
+  static bool attr_set = false;
+  const size_t lds = (size_t)2 * WG_BK * (BM + BN) * sizeof(float);
+  auto k = tapwgrad_kernel<BM, BN, WM, WN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, dim3(nitems), dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_tapwgrad(int cfg, const WgParams& p, int nitems, hipStream_t s) {
+  if (nitems <= 0) return hipSuccess;
+  switch (cfg) {
+    case WG_128x128: return launch_wg<128, 128, 2, 2>(p, nitems, s);
+    case WG_32x128: return launch_wg<32, 128, 1, 4>(p, nitems, s);
+    case WG_128x32: return launch_wg<128, 32, 4, 1>(p, nitems, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+// out[j] (+)= sum_s partial[s*slab_total + inv[j]]   (inv == nullptr: identity).  Fixed summation order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, long long slab_total,
+                                                           int nsplit, const int* __restrict__ inv,
+                                                           float* __restrict__ out, long long count, int accumulate) {
+  for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < count; j += (long long)gridDim.x * 256) {
+    const long long src = inv ? (long long)inv[j] : j;
+    float s = 0.f;
+    if (src >= 0)
+      for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * slab_total + src];
+    out[j] = accumulate ? out[j] + s : s;
+  }
+}
+hipError_t launch_wgrad_reduce(const float* partial, long long slab_total, int nsplit, const int* inv, float* out,
+                               long long count, int accumulate, hipStream_t s) {
+  int blocks = (int)std::min<long long>((count + 255) / 256, 8192);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, slab_total, nsplit, inv, out, count,
+                     accumulate);
+  return hipGetLastError();
+}
+
+// dst[i] = map[i] >= 0 ? src[map[i]] : 0   (reference-layout parameter -> packed slab, built on the device every step)
+__global__ __launch_bounds__(256) void gather_pack_kernel(const float* __restrict__ src, const int* __restrict__ map,
+                                                          float* __restrict__ dst, long long count) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+    const int m = map[i];
+    dst[i] = m >= 0 ? src[m] : 0.f;
+  }
+}
+hipError_t launch_gather_pack(const float* src, const int* map, float* dst, long long count, hipStream_t s) {
+  int blocks = (int)std::min<long long>((count + 255) / 256, 8192);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(gather_pack_kernel, dim3(blocks), dim3(256), 0, s, src, map, dst, count);
+  return hipGetLastError();
+}
+
+// ---- MDCL (layers.py:207-258): composite stencil <-> (W, coefficients) on the device -------------------------
+// slab_f[t][co][ci] = sum over the (branch b, pq) pairs that land on tap t of coeff_b[co] * W[co,ci,pq]
+//                     (+ tap 0: coeff_1x1[co] * mean_pq W[co,ci,:])          forward  [tap][CoutPad][CinPad]
+// slab_b[t][ci][co] = same value, transposed                                  backward [tap][CinPadB][CoutPadB]
+__global__ __launch_bounds__(256) void mdc_pack_kernel(MdcPackArgs a) {
+  const long long total = (long long)a.ntaps * a.cout * a.cin;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ci = (int)(i % a.cin);
+    const int co = (int)((i / a.cin) % a.cout);
+    const int t = (int)(i / ((long long)a.cin * a.cout));
+    const float* w = a.W + ((size_t)co * a.cin + ci) * 9;
+    float v = 0.f;
+    for (int e = a.tap_start[t]; e < a.tap_start[t + 1]; ++e) v += a.coeff[a.ent_branch[e]][co] * w[a.ent_pq[e]];
+    if (t == 0 && a.coeff_1x1) {
+      float m = 0.f;
+      for (int k = 0; k < 9; ++k) m += w[k];
+      v += a.coeff_1x1[co] * (m / 9.f);
+    }
+    a.slab_f[((size_t)t * a.f_rows + co) * a.f_cols + ci] = v;
+    a.slab_b[((size_t)t * a.b_rows + ci) * a.b_cols + co] = v;
+  }
+}
+hipError_t launch_mdc_pack(const MdcPackArgs& a, hipStream_t s) {
+  const long long total = (long long)a.ntaps * a.cout * a.cin;
+  int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(mdc_pack_kernel, dim3(blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// gradient of the composite stencil dS [tap][f_rows][f_cols] -> dW (Cout,Cin,3,3) and the per-filter coefficients
+//   dW[co,ci,pq]   = sum_b coeff_b[co] * dS[t(b,pq)][co][ci]  (+ coeff_1x1[co]/9 * dS[0][co][ci])
+//   dcoeff_b[co]   = sum_{ci,pq} W[co,ci,pq] * dS[t(b,pq)][co][ci];   dcoeff_1x1[co] = sum_ci mean_pq(W) * dS[0][co][ci]
+// one block per output filter co (coefficient sums reduced in LDS, fixed order).
+__global__ __launch_bounds__(256) void mdc_unpack_grad_kernel(MdcPackArgs a, const float* __restrict__ dS,
+                                                              float* __restrict__ dW, MdcCoeffGrads g, int accumulate) {
+  __shared__ float red[256];
+  const int co = blockIdx.x;
+  float part[MDC_MAX_BRANCH + 1];
+#pragma unroll
+  for (int b = 0; b <= MDC_MAX_BRANCH; ++b) part[b] = 0.f;
+  for (int ci = threadIdx.x; ci < a.cin; ci += 256) {
+    const float* w = a.W + ((size_t)co * a.cin + ci) * 9;
+    float dw[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dw[k] = 0.f;
+    for (int t = 0; t < a.ntaps; ++t) {
+      const float d = dS[((size_t)t * a.f_rows + co) * a.f_cols + ci];
+      for (int e = a.tap_start[t]; e < a.tap_start[t + 1]; ++e) {
+        const int b = a.ent_branch[e], pq = a.ent_pq[e];
+        dw[pq] += a.coeff[b][co] * d;
+        part[b] += w[pq] * d;
+      }
+      if (t == 0 && a.coeff_1x1) {
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          dw[k] += a.coeff_1x1[co] * d * (1.f / 9.f);
+          m += w[k];
+        }
+        part[MDC_MAX_BRANCH] += (m / 9.f) * d;
+      }
+    }
+    float* o = dW + ((size_t)co * a.cin + ci) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = accumulate ? o[k] + dw[k] : dw[k];
+  }
+  for (int b = 0; b <= MDC_MAX_BRANCH; ++b) {
+    float* dst = (b == MDC_MAX_BRANCH) ? g.d1x1 : (b < a.nbranch ? g.d[b] : nullptr);
+    if (!dst) continue;
+    red[threadIdx.x] = part[b];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) dst[co] = accumulate ? dst[co] + red[0] : red[0];
+    __syncthreads();
+  }
+}
+hipError_t launch_mdc_unpack_grad(const MdcPackArgs& a, const float* dS, float* dW, const MdcCoeffGrads& g,
+                                  int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(mdc_unpack_grad_kernel, dim3(a.cout), dim3(256), 0, s, a, dS, dW, g, accumulate);
+  return hipGetLastError();
+}
+
+}  // namespace ian

@@ -206,3 +206,48 @@ class Handle:
             self.close()
         except Exception:
             pass
+
+
+# ---- include/ian_train.h: layer objects + element-wise ops of the training step -------------------------------------
+_TRAIN_HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ian_train.h")
+_train_ready = False
+
+
+def parse_header_prototypes(path):
+    """[(return type, name, [argument C types])] of every function declared in a C header (plain C, one per ';')."""
+    import re
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"#.*", " ", text)
+    out = []
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(ian_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if "typedef" in ret:
+            continue
+        argt = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                argt.append("ptr" if "*" in a else a.rsplit(" ", 1)[0].replace("const ", "").strip())
+        out.append((ret, name, argt))
+    return out
+
+
+_CT = {"int32_t": C.c_int32, "int64_t": C.c_int64, "float": C.c_float, "int": C.c_int, "ptr": C.c_void_p}
+
+
+def load_train_library():
+    """libian.so with argtypes/restype of every include/ian_train.h entry point set from the header itself."""
+    global _train_ready
+    lib = load_library()
+    if not _train_ready:
+        for ret, name, argt in parse_header_prototypes(_TRAIN_HEADER):
+            fn = getattr(lib, name)
+            fn.argtypes = [_CT[t] for t in argt]
+            fn.restype = C.c_char_p if "char" in ret else (None if ret == "void" else (C.c_int64 if "int64" in ret else C.c_int32))
+        _train_ready = True
+    return lib
+
+
+def train_exports():
+    return [name for _, name, _ in parse_header_prototypes(_TRAIN_HEADER)]

@@ -1,0 +1,770 @@
+"""Training step of the full IAN on MI355X: the host-side equivalent of train_IAN.py:47-352
+(``make_training_functions`` -> ``update_gen`` / ``update_discrim``).
+
+The reference builds ONE Theano graph out of Lasagne layers and lets Theano differentiate it; here the same
+graph is wired explicitly, forward and backward, over the C ABI of include/ian_train.h: ``ian_layer_*`` objects
+for the conv / transposed-conv / MDCL / dense layers (forward, backward-data, backward-weight = the three cuDNN /
+GEMM calls Theano would emit) and ``ian_k_*`` launches for everything element-wise.  Python only sequences
+launches and owns the device buffers (torch tensors are containers; no torch arithmetic touches activations,
+gradients or parameters).
+
+Graph (train_IAN.py:116-149): encoder(X) -> z ~ N(mu, e^ls) -> IAF -> decoder -> X_hat; encoder(X_hat);
+decoder(IAF(Z)) -> X_gen; encoder(X_gen); every pass in batch-statistics batch-norm mode.
+Updates (train_IAN.py:253-276): three Adam groups -- encoder_params (discriminator step), decoder_params
+(generator step), Z_params (both).
+
+Data parallel: one process per GPU, the minibatch is sharded; gradients are summed with a bucketed
+RCCL all-reduce (``Comm``); with ``exact=True`` the batch-norm statistics are all-reduced and the MinibatchLayer
+activations all-gathered so that the N-GPU step is the same function of the global minibatch as the 1-GPU step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+from . import config_loader, made
+from .lib import OpDesc, load_train_library
+
+BN_EPS = 1e-4
+ACT = {"none": 0, "relu": 1, "lrelu": 2, "elu": 3, "tanh": 4, "sigmoid": 5}
+K_CONV, K_DECONV, K_MDC, K_DENSE = 1, 2, 3, 4
+
+ENC_WIDTHS = (128, 256, 512, 1024)
+DEC_STAGES = (("dec_conv1", 512, 512, 4, "dec_conv2a", [0, 2]), ("dec_conv2", 512, 256, 8, "dec_conv3a", [0, 2, 3]),
+              ("dec_conv3", 256, 128, 16, "dec_conv4a", [0, 2, 3]))   # (deconv, cin, cout, in_hw, block, scales) IAN.py:139-171
+HEAD_SCALES = [2, 3, 4]
+
+
+def cs(c):
+    return (c + 31) // 32 * 32
+
+
+def mdcl_names(name, scales):
+    return [name + "W", name + "_coeff_base"] + [name + ("_coeff_1x1" if s == 0 else "_coeff_%d" % s) for s in scales]
+
+
+# ======================================================================================================
+# communication (RCCL through torch.distributed; gloo in the CPU tests)
+# ======================================================================================================
+class Comm:
+    """Sum-all-reduce / all-gather for the data-parallel step.  ``bucket_bytes`` sizes the gradient buckets for
+    xGMI (point-to-point links: a few large messages)."""
+
+    def __init__(self, group=None, bucket_bytes=64 << 20):
+        import torch.distributed as dist
+        self.dist = dist
+        self.active = dist.is_available() and dist.is_initialized()
+        self.group = group
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
+        self.bucket_bytes = bucket_bytes
+
+    def all_reduce_sum(self, t, async_op=False):
+        if self.world == 1:
+            return None
+        return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def all_reduce_buckets(self, flat, async_op=False):
+        """flat: 1-D tensor; reduces it in bucket_bytes pieces; returns the work handles (async) or []."""
+        if self.world == 1:
+            return []
+        n = flat.numel()
+        step = max(1, self.bucket_bytes // flat.element_size())
+        works = []
+        for o in range(0, n, step):
+            w = self.dist.all_reduce(flat[o:min(n, o + step)], op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if async_op:
+                works.append(w)
+        return works
+
+    def all_gather_rows(self, local, out):
+        """out[(rank*n):(rank+1)*n] = local over all ranks (row blocks of equal size)."""
+        if self.world == 1:
+            out.copy_(local)
+            return
+        self.dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+
+
+# ======================================================================================================
+# thin wrappers over the C ABI
+# ======================================================================================================
+class IanTrainError(RuntimeError):
+    pass
+
+
+def _p(t):
+    if t is None:
+        return C.c_void_p(0)
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())
+
+
+class Layer:
+    """ian_layer (include/ian_train.h): one linear Lasagne layer with packed weights on the device."""
+
+    def __init__(self, lib, kind, cin, cout, in_h=1, in_w=1, scales=(), flat=(0, 0, 0), unflat=(0, 0, 0), deconv_flip=True):
+        self.lib = lib
+        d = OpDesc()
+        d.kind, d.cin, d.cout, d.in_h, d.in_w = kind, cin, cout, in_h, in_w
+        d.src = d.dst = 0
+        d.src2 = d.src3 = -1
+        d.flat_c, d.flat_h, d.flat_w = flat
+        d.unflat_c, d.unflat_h, d.unflat_w = unflat
+        d.n_scales = len(scales)
+        for i, s in enumerate(scales):
+            d.scales[i] = s
+        self.h = C.c_void_p()
+        rc = lib.ian_layer_create(C.byref(d), int(bool(deconv_flip)), C.byref(self.h))
+        if rc != 0:
+            raise IanTrainError("ian_layer_create failed (%d)%s" % (rc, ": no HIP device, libian has no CPU fallback" if rc == -10 else ""))
+        self.kind, self.cin, self.cout = kind, cin, cout
+        self.nparams = lib.ian_layer_num_params(self.h)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise IanTrainError("libian layer error %d: %s" % (rc, (self.lib.ian_layer_last_error(self.h) or b"?").decode()))
+
+    def _ptrs(self, tensors):
+        arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        return arr
+
+    def set_params(self, tensors, stream=0):
+        self._chk(self.lib.ian_layer_set_params(self.h, self._ptrs(tensors), len(tensors), C.c_void_p(stream)))
+
+    def forward(self, x, n, y, y_stride=0, bias=None, res=None, act=0, stream=0):
+        self._chk(self.lib.ian_layer_forward(self.h, _p(x), n, _p(y), y_stride, _p(bias), _p(res), act, C.c_void_p(stream)))
+
+    def backward_data(self, dy, n, dx, dx_stride=0, accumulate=False, stream=0):
+        self._chk(self.lib.ian_layer_backward_data(self.h, _p(dy), n, _p(dx), dx_stride, int(accumulate), C.c_void_p(stream)))
+
+    def backward_weight(self, x, dy, n, dparams, accumulate=False, stream=0):
+        self._chk(self.lib.ian_layer_backward_weight(self.h, _p(x), _p(dy), n, self._ptrs(dparams), len(dparams), int(accumulate),
+                                                     C.c_void_p(stream)))
+
+    def close(self):
+        if self.h:
+            self.lib.ian_layer_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class K:
+    """ian_k_* launches with tensor arguments."""
+
+    def __init__(self, lib, stream=0):
+        self.lib = lib
+        self.stream = C.c_void_p(stream)
+
+    def __getattr__(self, name):
+        fn = getattr(self.lib, "ian_k_" + name)
+
+        def call(*args):
+            conv = []
+            for a, t in zip(args, fn.argtypes):
+                if t is C.c_void_p:
+                    conv.append(_p(a))
+                else:
+                    conv.append(a)
+            rc = fn(*conv, self.stream)
+            if rc != 0:
+                raise IanTrainError("ian_k_%s failed (%d): %s" % (name, rc, (self.lib.ian_k_last_error() or b"?").decode()))
+        return call
+
+
+# ======================================================================================================
+# parameter store: three Adam groups as flat device buffers, reference (Theano) layouts and names
+# ======================================================================================================
+class ParamGroup:
+    def __init__(self, torch, names, shapes, device):
+        self.names = list(names)
+        self.offsets = {}
+        o = 0
+        for n in self.names:
+            cnt = int(np.prod(shapes[n]))
+            self.offsets[n] = (o, cnt, tuple(shapes[n]))
+            o += (cnt + 3) // 4 * 4   # keep every tensor 16-byte aligned
+        self.numel = o
+        self.p = torch.zeros(o, dtype=torch.float32, device=device)
+        self.g = torch.zeros_like(self.p)
+        self.m = torch.zeros_like(self.p)
+        self.v = torch.zeros_like(self.p)
+        self.t = 0
+
+    def view(self, buf, name):
+        o, cnt, shape = self.offsets[name]
+        return buf[o:o + cnt]
+
+
+class BN:
+    """Lasagne batch_norm in training mode (App. B.3): state of one normalisation in one pass."""
+
+    def __init__(self, torch, C, device):
+        self.C = C
+        z = lambda: torch.zeros(C, dtype=torch.float32, device=device)
+        self.sums, self.bsums = torch.zeros(2 * C, dtype=torch.float32, device=device), torch.zeros(2 * C, dtype=torch.float32, device=device)
+        self.mean, self.inv_std, self.scale, self.shift = z(), z(), z(), z()
+        self.count = 1.0
+
+
+class Trainer:
+    """update_gen / update_discrim of train_IAN.py on one GPU (or one rank of a data-parallel job)."""
+
+    def __init__(self, config_path, params, batch, comm=None, exact=True, device="cuda", deconv_flip=True):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise IanTrainError("the training step needs an MI355X: libian has no CPU fallback")
+        self.lib = load_train_library()
+        self.dev = torch.device(device)
+        mod = config_loader.load_config(config_path)
+        self.cfg = dict(mod.cfg)
+        for k in ("l_IAF_mu", "l_Z_IAF"):
+            pass
+        c = self.cfg
+        self.n = int(batch)                      # per-rank batch
+        self.comm = comm or Comm()
+        self.exact = bool(exact) and self.comm.world > 1
+        self.N = self.n * self.comm.world        # global batch (losses are means over it)
+        self.k = K(self.lib, 0)
+        self.lr = float(c["learning_rate"][0] if isinstance(c["learning_rate"], dict) else c["learning_rate"])
+        self.zdim = int(c["num_latents"])
+        self._build_params(params)
+        self._build_layers(deconv_flip)
+        self._alloc()
+        self.touched = set()
+
+    # ---------------------------------------------------------------------------------------------
+    def _build_params(self, P):
+        torch = self.torch
+        shapes = {k: tuple(np.shape(v)) for k, v in P.items()}
+        enc = ["enc_conv1.W", "enc_conv1.b"]
+        for i in (2, 3, 4):
+            enc += ["enc_conv%d.W" % i, "bnorm%d.beta" % i, "bnorm%d.gamma" % i]
+        enc += ["minibatch_discrim.theta", "minibatch_discrim.log_weight_scale", "minibatch_discrim.b", "discrimi.W"]
+        zp = ["enc_fc1.W", "bnorm_enc_fc1.beta", "bnorm_enc_fc1.gamma", "enc_mu.W", "mu_bnorm.beta", "mu_bnorm.gamma",
+              "enc_logsigma.W", "ls_bnorm.beta", "ls_bnorm.gamma"]
+        dec = ["l_dec_fc2.W", "l_dec_fc2.b"]
+        for dc, ci, co, hw, blk, sc in DEC_STAGES:
+            dec.append(dc + ".W")
+            dec += [blk + "bnorm0.beta", blk + "bnorm0.gamma"] + mdcl_names(blk, sc)
+            dec += [blk + "bnorm1.beta", blk + "bnorm1.gamma"] + mdcl_names(blk + "2", sc)
+            dec += [blk + "bnorm2.beta", blk + "bnorm2.gamma"]
+        dec += ["dec_conv4.W", "bnorm_dc4.beta", "bnorm_dc4.gamma"]
+        for h in ("R", "G_a", "G_b", "B_a", "B_b"):
+            dec += mdcl_names(h, HEAD_SCALES)
+        self.groups = {"enc": ParamGroup(torch, enc, shapes, self.dev), "Z": ParamGroup(torch, zp, shapes, self.dev),
+                       "dec": ParamGroup(torch, dec, shapes, self.dev)}
+        self.where = {}
+        for gname, g in self.groups.items():
+            for nme in g.names:
+                if nme not in P:
+                    raise IanTrainError("missing parameter %s" % nme)
+                self.where[nme] = gname
+                g.view(g.p, nme).copy_(torch.from_numpy(np.ascontiguousarray(P[nme], np.float32).ravel()))
+        # MADE x2: never trained (train_IAN.py:184-194) -> pre-masked constants (layers.py:671,703)
+        masks = made.masks_once(self.zdim)
+        w, b = [], []
+        for m in ("l_IAF_mu", "l_IAF_ls"):
+            for l, mk in zip(("_input", "_output_W", "_output_D"), masks):
+                w.append(np.asarray(P[m + l + ".W"], np.float32) * mk)
+                b.append(np.asarray(P[m + l + ".b"], np.float32))
+        self.made_w = torch.from_numpy(np.stack(w)).to(self.dev).contiguous()
+        self.made_b = torch.from_numpy(np.stack(b)).to(self.dev).contiguous()
+        # l_dec_fc2 output is stored (H,W,C) while its bias is indexed (C,H,W) (App. B.6)
+        Cc, Hh, Ww = 512, 4, 4
+        idx = np.arange(Cc * Hh * Ww).reshape(Cc, Hh, Ww).transpose(1, 2, 0).ravel()      # hwc position -> chw index
+        self.fc2_perm = torch.from_numpy(idx.astype(np.int32)).to(self.dev)
+        inv = np.empty_like(idx)
+        inv[idx] = np.arange(idx.size)
+        self.fc2_inv = torch.from_numpy(inv.astype(np.int32)).to(self.dev)                 # chw index -> hwc position
+
+    def P(self, name):
+        g = self.groups[self.where[name]]
+        return g.view(g.p, name)
+
+    def G(self, name):
+        g = self.groups[self.where[name]]
+        return g.view(g.g, name)
+
+    def _build_layers(self, flip):
+        L = lambda *a, **kw: Layer(self.lib, *a, deconv_flip=flip, **kw)
+        self.layers = {}
+        cin = 3
+        for i, w in enumerate(ENC_WIDTHS):
+            self.layers["enc_conv%d" % (i + 1)] = (L(K_CONV, cin, w, 64 >> i, 64 >> i), ["enc_conv%d.W" % (i + 1)])
+            cin = w
+        self.layers["enc_fc1"] = (L(K_DENSE, 16384, 1000, flat=(1024, 4, 4)), ["enc_fc1.W"])
+        self.layers["enc_mu"] = (L(K_DENSE, 1000, self.zdim), ["enc_mu.W"])
+        self.layers["enc_logsigma"] = (L(K_DENSE, 1000, self.zdim), ["enc_logsigma.W"])
+        self.layers["mb"] = (L(K_DENSE, 1024, 2500), None)   # weights = normalised theta (layers.py:494)
+        self.layers["l_dec_fc2"] = (L(K_DENSE, self.zdim, 8192, unflat=(512, 4, 4)), ["l_dec_fc2.W"])
+        for dc, ci, co, hw, blk, sc in DEC_STAGES:
+            self.layers[dc] = (L(K_DECONV, ci, co, hw, hw), [dc + ".W"])
+            self.layers[blk] = (L(K_MDC, co, co, 2 * hw, 2 * hw, scales=sc), mdcl_names(blk, sc))
+            self.layers[blk + "2"] = (L(K_MDC, co, co, 2 * hw, 2 * hw, scales=sc), mdcl_names(blk + "2", sc))
+        self.layers["dec_conv4"] = (L(K_DECONV, 128, 128, 32, 32), ["dec_conv4.W"])
+        for h, ci in (("R", 128), ("G_a", 128), ("G_b", 2), ("B_a", 128), ("B_b", 4)):
+            self.layers[h] = (L(K_MDC, ci, 2, 64, 64, scales=HEAD_SCALES), mdcl_names(h, HEAD_SCALES))
+
+    def _alloc(self):
+        torch = self.torch
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+        self.ws_stats = z(256 * 2 * 8192)
+        self.ws_loss = z(1024 * 2)
+        self.scalars = z(64)
+        self.mb_W = z(1024 * 2500)
+        self.mb_dW = z(1024 * 2500)
+        self.mb_colscale = z(2500)
+        self.tmp_vals = z(2048)
+
+    # ---------------------------------------------------------------------------------------------
+    # parameter refresh (after every optimiser update): reference layout -> kernel layouts
+    # ---------------------------------------------------------------------------------------------
+    def refresh_weights(self):
+        k = self.k
+        for name, (layer, pnames) in self.layers.items():
+            if pnames is None:
+                continue
+            layer.set_params([self.P(n) for n in pnames])
+        k.mb_weight(self.P("minibatch_discrim.theta"), self.P("minibatch_discrim.log_weight_scale"), self.mb_W, self.mb_colscale,
+                    1024, 2500)
+        self.layers["mb"][0].set_params([self.mb_W])
+        self.fc2_bias = self.torch.empty(8192, dtype=self.torch.float32, device=self.dev)
+        k.gather(self.P("l_dec_fc2.b"), self.fc2_perm, self.fc2_bias, 8192)
+
+    # ---------------------------------------------------------------------------------------------
+    # building blocks
+    # ---------------------------------------------------------------------------------------------
+    def _bn_forward(self, bn, y, a, rows, C, stride, gamma, beta, act, count_rows):
+        """batch statistics over this pass (all ranks when exact) -> a = act(bn(y))."""
+        k = self.k
+        k.colstats(0, y, None, None, None, None, rows, C, stride, 0, self.ws_stats, min(256, rows), bn.sums)
+        if self.exact:
+            self.comm.all_reduce_sum(bn.sums)
+        bn.count = float(count_rows * (self.comm.world if self.exact else 1))
+        k.bn_make_affine(bn.sums, bn.count, BN_EPS, gamma, beta, C, bn.mean, bn.inv_std, bn.scale, bn.shift)
+        k.affine(y, a, bn.scale, bn.shift, rows, C, stride, act)
+
+    def _bn_backward(self, bn, dA, a, y, dy, rows, C, stride, act, gname, bname, want_w):
+        k = self.k
+        k.colstats(1, dA, a, y, bn.mean, bn.inv_std, rows, C, stride, act, self.ws_stats, min(256, rows), bn.bsums)
+        if self.exact:
+            self.comm.all_reduce_sum(bn.bsums)
+        if want_w:
+            # with exact statistics every rank already holds the GLOBAL dbeta/dgamma: pre-divide so that the
+            # gradient all-reduce (a sum over ranks) restores them
+            sc = 1.0 / self.comm.world if self.exact else 1.0
+            self._acc(bname, bn.bsums[:C], sc)
+            self._acc(gname, bn.bsums[C:], sc)
+        k.bn_bwd(dA, a, y, bn.mean, bn.inv_std, bn.scale, bn.bsums, bn.count, dy, rows, C, stride, act)
+
+    def _acc(self, pname, src, alpha=1.0):
+        """grad[pname] (+)= alpha * src"""
+        self.k.axpy(float(alpha), src, self.G(pname), src.numel(), int(pname in self.touched))
+        self.touched.add(pname)
+
+    def _wgrad(self, lname, x, dy, n):
+        layer, pnames = self.layers[lname]
+        acc = pnames[0] in self.touched
+        layer.backward_weight(x, dy, n, [self.G(p) for p in pnames], accumulate=acc)
+        self.touched.update(pnames)
+
+    # ---------------------------------------------------------------------------------------------
+    # encoder pass (IAN.py:71-110 + discriminator head :209-216), training mode
+    # ---------------------------------------------------------------------------------------------
+    def enc_alloc(self):
+        torch, n = self.torch, self.n
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+        E = {"x": z(n, 64, 64, 32), "dx": z(n, 64, 64, 32)}
+        for i, w in enumerate(ENC_WIDTHS):
+            hw = 32 >> i
+            E["a%d" % (i + 1)] = z(n, hw, hw, w)
+            E["da%d" % (i + 1)] = z(n, hw, hw, w)
+            if i > 0:
+                E["y%d" % (i + 1)] = z(n, hw, hw, w)
+                E["bn%d" % (i + 1)] = BN(torch, w, self.dev)
+        E["feat"], E["dfeat"] = z(n, 1024), z(n, 1024)
+        E["act"], E["dact"] = z(n, cs(2500)), z(n, cs(2500))
+        E["act_all"] = z(self.N if self.exact else n, cs(2500))
+        E["mb"], E["dmb"] = z(n, cs(1524)), z(n, cs(1524))
+        E["dmb_all"] = z(self.N if self.exact else n, cs(1524))
+        E["p"], E["loss"], E["dlogits"] = z(n, 3), z(n, 4), z(n, 4)
+        return E
+
+    def enc_forward(self, E, x_nchw, targets=(-1, -1), acc_target=0):
+        """x_nchw: (n,3,64,64) device tensor.  targets: classes whose -log p is recorded in E['loss'][:, 0:2]."""
+        k, n = self.k, self.n
+        k.nchw_to_nhwc(x_nchw, E["x"], n, 4096, 3, 32)
+        self.layers["enc_conv1"][0].forward(E["x"], n, E["a1"], bias=self.P("enc_conv1.b"), act=ACT["lrelu"])
+        for i in (2, 3, 4):
+            w, hw = ENC_WIDTHS[i - 1], 64 >> i
+            self.layers["enc_conv%d" % i][0].forward(E["a%d" % (i - 1)], n, E["y%d" % i])
+            self._bn_forward(E["bn%d" % i], E["y%d" % i], E["a%d" % i], n * hw * hw, w, w, self.P("bnorm%d.gamma" % i),
+                             self.P("bnorm%d.beta" % i), ACT["lrelu"], n * hw * hw)
+        k.globalpool(E["a4"], E["feat"], n, 16, 1024, 1024, 1024)
+        self.layers["mb"][0].forward(E["feat"], n, E["act"], y_stride=cs(2500))
+        row0 = 0
+        if self.exact:
+            self.comm.all_gather_rows(E["act"], E["act_all"])
+            row0 = self.comm.rank * n
+        else:
+            E["act_all"] = E["act"]
+        E["row0"] = row0
+        k.mb_forward(E["act_all"], E["act_all"].shape[0], cs(2500), row0, n, 500, 5, self.P("minibatch_discrim.b"), E["feat"], 1024,
+                     1024, E["mb"], cs(1524))
+        k.disc_head(E["mb"], cs(1524), 1524, self.P("discrimi.W"), n, targets[0], targets[1], acc_target, E["p"], E["loss"])
+
+    def enc_backward(self, E, ce, feature_seeded, want_w, want_dx):
+        """ce = (target0, w0, target1, w1): dlogits = sum w_t (p - onehot(target_t)).  feature_seeded: da1..da4 already
+        hold the feature-loss seeds (train_IAN.py:244).  want_w: accumulate encoder_params gradients."""
+        k, n = self.k, self.n
+        t0, w0, t1, w1 = ce
+        k.disc_head_bwd(E["p"], self.P("discrimi.W"), 1524, n, t0, float(w0), t1, float(w1), E["dlogits"], E["dmb"], cs(1524))
+        if want_w:
+            k.disc_head_wgrad(E["mb"], cs(1524), 1524, n, E["dlogits"], self.G("discrimi.W"), int("discrimi.W" in self.touched))
+            self.touched.add("discrimi.W")
+            # db[k] = sum_b df[b,k] : column sums of dmb[:, 1024:1524]
+            k.colstats(2, E["dmb"].view(-1)[1024:], None, None, None, None, n, 500, cs(1524), 0, self.ws_stats, min(256, n), self.tmp_vals)
+            self._acc("minibatch_discrim.b", self.tmp_vals[:500])
+        dmb_all = E["dmb"]
+        if self.exact:
+            self.comm.all_gather_rows(E["dmb"], E["dmb_all"])
+            dmb_all = E["dmb_all"]
+        k.mb_backward(E["act_all"], E["act_all"].shape[0], cs(2500), E["row0"], n, 500, 5, dmb_all.view(-1)[1024:], cs(1524), E["dact"],
+                      cs(2500))
+        k.grad_pass(E["dmb"], cs(1524), 0, E["dfeat"], None, 1024, n, 1024, 0, 0)           # direct path of the concat (:524)
+        self.layers["mb"][0].backward_data(E["dact"], n, E["dfeat"], dx_stride=1024, accumulate=True)
+        if want_w:
+            self.layers["mb"][0].backward_weight(E["feat"], E["dact"], n, [self.mb_dW], accumulate=False)
+            acc = int("minibatch_discrim.theta" in self.touched)
+            k.mb_weight_bwd(self.P("minibatch_discrim.theta"), self.mb_colscale, self.mb_dW, self.G("minibatch_discrim.theta"),
+                            self.G("minibatch_discrim.log_weight_scale"), 1024, 2500, acc)
+            self.touched.update(("minibatch_discrim.theta", "minibatch_discrim.log_weight_scale"))
+        k.globalpool_bwd(E["dfeat"], E["da4"], n, 16, 1024, 1024, 1024, int(feature_seeded))
+        for i in (4, 3, 2):
+            w, hw = ENC_WIDTHS[i - 1], 64 >> i
+            da, a, y = E["da%d" % i], E["a%d" % i], E["y%d" % i]
+            self._bn_backward(E["bn%d" % i], da, a, y, da, n * hw * hw, w, w, ACT["lrelu"], "bnorm%d.gamma" % i, "bnorm%d.beta" % i, want_w)
+            if want_w:
+                self._wgrad("enc_conv%d" % i, E["a%d" % (i - 1)], da, n)
+            self.layers["enc_conv%d" % i][0].backward_data(da, n, E["da%d" % (i - 1)], accumulate=feature_seeded)
+        # enc_conv1: bias + lrelu, no batch-norm (IAN.py:71-80)
+        if want_w:
+            k.colstats(2, E["da1"], E["a1"], None, None, None, n * 1024, 128, 128, ACT["lrelu"], self.ws_stats, 256, self.tmp_vals)
+            self._acc("enc_conv1.b", self.tmp_vals[:128])
+        k.bn_bwd(E["da1"], E["a1"], None, None, None, None, None, 1.0, E["da1"], n * 1024, 128, 128, ACT["lrelu"])
+        if want_w:
+            self._wgrad("enc_conv1", E["x"], E["da1"], n)
+        if want_dx:
+            self.layers["enc_conv1"][0].backward_data(E["da1"], n, E["dx"], accumulate=False)
+
+    # ---------------------------------------------------------------------------------------------
+    # latent path (IAN.py:114-128): enc_fc1 -> (mu, logsigma) -> z0 = mu + e^ls * eps -> IAF
+    # ---------------------------------------------------------------------------------------------
+    def z_alloc(self):
+        torch, n = self.torch, self.n
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+        Z = {"y_fc1": z(n, 1024), "f": z(n, 1024), "df": z(n, 1024), "bn_fc1": BN(torch, 1000, self.dev)}
+        for nm in ("mu", "ls"):
+            Z["y_" + nm], Z[nm], Z["d" + nm] = z(n, 128), z(n, 128), z(n, 128)
+            Z["bn_" + nm] = BN(torch, 100, self.dev)
+        Z["z0"], Z["z"], Z["dz0"], Z["dz"], Z["kl"] = z(n, 128), z(n, 128), z(n, 128), z(n, 128), z(n, 100)
+        return Z
+
+    def z_forward(self, Zs, a4, eps):
+        k, n = self.k, self.n
+        self.layers["enc_fc1"][0].forward(a4, n, Zs["y_fc1"], y_stride=1024)
+        self._bn_forward(Zs["bn_fc1"], Zs["y_fc1"], Zs["f"], n, 1000, 1024, self.P("bnorm_enc_fc1.gamma"), self.P("bnorm_enc_fc1.beta"),
+                         ACT["relu"], n)
+        for nm, ln, bn in (("mu", "enc_mu", "mu_bnorm"), ("ls", "enc_logsigma", "ls_bnorm")):
+            self.layers[ln][0].forward(Zs["f"], n, Zs["y_" + nm], y_stride=128)
+            self._bn_forward(Zs["bn_" + nm], Zs["y_" + nm], Zs[nm], n, 100, 128, self.P(bn + ".gamma"), self.P(bn + ".beta"), 0, n)
+        k.sample(Zs["mu"], Zs["ls"], eps, Zs["z0"], Zs["kl"], n, 100, 128, eps.shape[1])
+        k.made_iaf(Zs["z0"], Zs["z"], self.made_w, self.made_b, n, 100, 128)
+
+    def z_backward(self, Zs, a4):
+        """Zs['dz'] = dL/dz (from the decoder) -> gradients of Z_params, including KL and the L2 penalty."""
+        k, n = self.k, self.n
+        k.made_iaf_bwd(Zs["z0"], Zs["dz"], Zs["dz0"], self.made_w, self.made_b, n, 100, 128)
+        klw = 1.0 / (self.N * 100.0)        # d(-0.5*mean(...)) : factor folded in the kernel's formula
+        k.sample_bwd(Zs["mu"], Zs["ls"], Zs["eps"], Zs["dz0"], Zs["dmu"], Zs["dls"], n, 100, 128, Zs["eps"].shape[1], klw)
+        first = True
+        for nm, ln, bn in (("mu", "enc_mu", "mu_bnorm"), ("ls", "enc_logsigma", "ls_bnorm")):
+            d = Zs["d" + nm]
+            self._bn_backward(Zs["bn_" + nm], d, None, Zs["y_" + nm], d, n, 100, 128, 0, bn + ".gamma", bn + ".beta", True)
+            self._wgrad(ln, Zs["f"], d, n)
+            self.layers[ln][0].backward_data(d, n, Zs["df"], dx_stride=1024, accumulate=not first)
+            first = False
+        self._bn_backward(Zs["bn_fc1"], Zs["df"], Zs["f"], Zs["y_fc1"], Zs["df"], n, 1000, 1024, ACT["relu"], "bnorm_enc_fc1.gamma",
+                          "bnorm_enc_fc1.beta", True)
+        self._wgrad("enc_fc1", a4, Zs["df"], n)
+
+    # ---------------------------------------------------------------------------------------------
+    # decoder pass (IAN.py:129-207), training mode
+    # ---------------------------------------------------------------------------------------------
+    def dec_alloc(self):
+        torch, n = self.torch, self.n
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+        D = {"h0": z(n, 4, 4, 512), "dh0": z(n, 4, 4, 512)}
+        for dc, ci, co, hw, blk, sc in DEC_STAGES:
+            s = 2 * hw
+            for nm in ("x", "a", "b", "c", "e", "h"):
+                D[blk + "_" + nm] = z(n, s, s, co)
+            for nm in ("dx", "da", "dc", "dh"):
+                D[blk + "_" + nm] = z(n, s, s, co)
+            for j in range(3):
+                D[blk + "_bn%d" % j] = BN(torch, co, self.dev)
+        D["y4"], D["h4"], D["dh4"], D["bn4"] = z(n, 64, 64, 128), z(n, 64, 64, 128), z(n, 64, 64, 128), BN(torch, 128, self.dev)
+        for nm in ("R", "G", "B", "Ga", "Ba", "RG", "gR", "gG", "gB", "dRG", "dRt"):
+            D[nm] = z(n, 64, 64, 32)
+        D["xhat"], D["dxhat"], D["tmp_img"] = z(n, 3, 64, 64), z(n, 3, 64, 64), z(n, 3, 64, 64)
+        D["dz"] = z(n, 128)
+        return D
+
+    def dec_forward(self, D, zbuf):
+        k, n = self.k, self.n
+        lay = lambda nme: self.layers[nme][0]
+        lay("l_dec_fc2").forward(zbuf, n, D["h0"], y_stride=8192, bias=self.fc2_bias, act=ACT["lrelu"])
+        h = D["h0"]
+        for dc, ci, co, hw, blk, sc in DEC_STAGES:
+            s = 2 * hw
+            rows = n * s * s
+            g = lambda j, t: self.P("%sbnorm%d.%s" % (blk, j, t))
+            lay(dc).forward(h, n, D[blk + "_x"])
+            self._bn_forward(D[blk + "_bn0"], D[blk + "_x"], D[blk + "_a"], rows, co, co, g(0, "gamma"), g(0, "beta"), ACT["lrelu"], rows)
+            lay(blk).forward(D[blk + "_a"], n, D[blk + "_b"])
+            self._bn_forward(D[blk + "_bn1"], D[blk + "_b"], D[blk + "_c"], rows, co, co, g(1, "gamma"), g(1, "beta"), ACT["lrelu"], rows)
+            lay(blk + "2").forward(D[blk + "_c"], n, D[blk + "_e"], res=D[blk + "_x"])       # ElemwiseSum (layers.py:415)
+            self._bn_forward(D[blk + "_bn2"], D[blk + "_e"], D[blk + "_h"], rows, co, co, g(2, "gamma"), g(2, "beta"), ACT["lrelu"], rows)
+            h = D[blk + "_h"]
+        rows = n * 4096
+        lay("dec_conv4").forward(h, n, D["y4"])
+        self._bn_forward(D["bn4"], D["y4"], D["h4"], rows, 128, 128, self.P("bnorm_dc4.gamma"), self.P("bnorm_dc4.beta"), ACT["lrelu"], rows)
+        sg = ACT["sigmoid"]
+        lay("R").forward(D["h4"], n, D["R"], act=sg)                                          # IAN.py:183-186
+        lay("G_a").forward(D["h4"], n, D["Ga"])
+        lay("G_b").forward(D["R"], n, D["G"], res=D["Ga"], act=sg)                            # :187-196
+        lay("B_a").forward(D["h4"], n, D["Ba"])
+        k.concat2(D["R"], 2, 32, D["G"], 2, 32, D["RG"], 32, rows)                            # :201
+        lay("B_b").forward(D["RG"], n, D["B"], res=D["Ba"], act=sg)                           # :197-206
+        k.beta(D["R"], D["G"], D["B"], D["xhat"], n, 4096, 32)                                # :207
+
+    def dec_backward(self, D, zbuf, want_w, want_dz):
+        """D['dxhat'] (NCHW) -> gradients of decoder_params (want_w) and D['dz'] (want_dz)."""
+        k, n = self.k, self.n
+        lay = lambda nme: self.layers[nme][0]
+        rows = n * 4096
+        sg = ACT["sigmoid"]
+        k.beta_bwd(D["dxhat"], D["R"], D["G"], D["B"], D["gR"], D["gG"], D["gB"], n, 4096, 32, sg)
+        # B = sigmoid(B_a(h4) + B_b([R,G]))
+        if want_w:
+            self._wgrad("B_b", D["RG"], D["gB"], n)
+            self._wgrad("B_a", D["h4"], D["gB"], n)
+        lay("B_b").backward_data(D["gB"], n, D["dRG"])
+        lay("B_a").backward_data(D["gB"], n, D["dh4"])
+        k.grad_pass(D["dRG"], 32, 0, D["gR"], D["R"], 32, rows, 2, sg, 1)
+        k.grad_pass(D["dRG"], 32, 2, D["gG"], D["G"], 32, rows, 2, sg, 1)
+        # G = sigmoid(G_a(h4) + G_b(R))
+        if want_w:
+            self._wgrad("G_b", D["R"], D["gG"], n)
+            self._wgrad("G_a", D["h4"], D["gG"], n)
+        lay("G_b").backward_data(D["gG"], n, D["dRt"])
+        k.grad_pass(D["dRt"], 32, 0, D["gR"], D["R"], 32, rows, 2, sg, 1)
+        lay("G_a").backward_data(D["gG"], n, D["dh4"], accumulate=True)
+        # R = sigmoid(R(h4))
+        if want_w:
+            self._wgrad("R", D["h4"], D["gR"], n)
+        lay("R").backward_data(D["gR"], n, D["dh4"], accumulate=True)
+        # dec_conv4 + bnorm_dc4 + lrelu
+        self._bn_backward(D["bn4"], D["dh4"], D["h4"], D["y4"], D["dh4"], rows, 128, 128, ACT["lrelu"], "bnorm_dc4.gamma", "bnorm_dc4.beta", want_w)
+        prev_h = D[DEC_STAGES[-1][4] + "_h"]
+        if want_w:
+            self._wgrad("dec_conv4", prev_h, D["dh4"], n)
+        lay("dec_conv4").backward_data(D["dh4"], n, D[DEC_STAGES[-1][4] + "_dh"])
+        for si in range(len(DEC_STAGES) - 1, -1, -1):
+            dc, ci, co, hw, blk, sc = DEC_STAGES[si]
+            s = 2 * hw
+            r = n * s * s
+            bnn = lambda j, t: "%sbnorm%d.%s" % (blk, j, t)
+            dh, dx, da, dcg = D[blk + "_dh"], D[blk + "_dx"], D[blk + "_da"], D[blk + "_dc"]
+            # h = lrelu(bn2(x + d)),  d = MDCL2(c)
+            self._bn_backward(D[blk + "_bn2"], dh, D[blk + "_h"], D[blk + "_e"], dh, r, co, co, ACT["lrelu"], bnn(2, "gamma"), bnn(2, "beta"), want_w)
+            if want_w:
+                self._wgrad(blk + "2", D[blk + "_c"], dh, n)
+            lay(blk + "2").backward_data(dh, n, dcg)
+            self._bn_backward(D[blk + "_bn1"], dcg, D[blk + "_c"], D[blk + "_b"], dcg, r, co, co, ACT["lrelu"], bnn(1, "gamma"), bnn(1, "beta"), want_w)
+            if want_w:
+                self._wgrad(blk, D[blk + "_a"], dcg, n)
+            lay(blk).backward_data(dcg, n, da)
+            self._bn_backward(D[blk + "_bn0"], da, D[blk + "_a"], D[blk + "_x"], dx, r, co, co, ACT["lrelu"], bnn(0, "gamma"), bnn(0, "beta"), want_w)
+            k.axpy(1.0, dh, dx, dx.numel(), 1)                                               # residual edge: dx += d(x+d)
+            src = D["h0"] if si == 0 else D[DEC_STAGES[si - 1][4] + "_h"]
+            if want_w:
+                self._wgrad(dc, src, dx, n)
+            lay(dc).backward_data(dx, n, D["dh0"] if si == 0 else D[DEC_STAGES[si - 1][4] + "_dh"])
+        # l_dec_fc2: bias + lrelu
+        k.bn_bwd(D["dh0"], D["h0"], None, None, None, None, None, 1.0, D["dh0"], n, 8192, 8192, ACT["lrelu"])
+        if want_w:
+            self._wgrad("l_dec_fc2", zbuf, D["dh0"], n)
+            k.colstats(2, D["dh0"], None, None, None, None, n, 8192, 8192, 0, self.ws_stats, min(256, n), self.tmp_vals_big())
+            k.gather(self.tmp_vals_big(), self.fc2_inv, self._fc2_db(), 8192)
+            self._acc("l_dec_fc2.b", self._fc2_db())
+        if want_dz:
+            lay("l_dec_fc2").backward_data(D["dh0"], n, D["dz"], dx_stride=128)
+
+    def tmp_vals_big(self):
+        if not hasattr(self, "_tvb"):
+            self._tvb = self.torch.zeros(2 * 8192, dtype=self.torch.float32, device=self.dev)
+        return self._tvb
+
+    def _fc2_db(self):
+        if not hasattr(self, "_fdb"):
+            self._fdb = self.torch.zeros(8192, dtype=self.torch.float32, device=self.dev)
+        return self._fdb
+
+    # ---------------------------------------------------------------------------------------------
+    # the step
+    # ---------------------------------------------------------------------------------------------
+    def _ensure_passes(self):
+        if hasattr(self, "EX"):
+            return
+        self.EX, self.EH, self.EG = self.enc_alloc(), self.enc_alloc(), self.enc_alloc()
+        self.ZS = self.z_alloc()
+        self.DZ, self.DG = self.dec_alloc(), self.dec_alloc()
+        self.zgen = self.torch.zeros(self.n, 128, dtype=self.torch.float32, device=self.dev)
+        self.zgen0 = self.torch.zeros(self.n, 128, dtype=self.torch.float32, device=self.dev)
+
+    def forward(self, X, Z, eps):
+        """The three passes of train_IAN.py:116-149.  X (n,3,64,64), Z (n,100), eps (n,100): device tensors."""
+        k, n = self.k, self.n
+        self._ensure_passes()
+        self.refresh_weights()
+        self.X = X
+        self.enc_forward(self.EX, X, targets=(0, -1), acc_target=0)                           # p_X vs p1
+        self.ZS["eps"] = eps
+        self.z_forward(self.ZS, self.EX["a4"], eps)
+        self.dec_forward(self.DZ, self.ZS["z"])                                                # X_hat
+        self.enc_forward(self.EH, self.DZ["xhat"], targets=(0, 1), acc_target=1)               # p_X_hat vs p1 (gen) / p2 (discrim)
+        k.grad_pass(Z, Z.shape[1], 0, self.zgen0, None, 128, n, 100, 0, 0)                     # (n,100) -> padded rows
+        k.made_iaf(self.zgen0, self.zgen, self.made_w, self.made_b, n, 100, 128)               # {l_Z_IAF: Z} (:149)
+        self.dec_forward(self.DG, self.zgen)                                                   # X_gen
+        self.enc_forward(self.EG, self.DG["xhat"], targets=(0, 2), acc_target=2)               # p_X_gen vs p1 / p3
+
+    def metrics(self):
+        """All scalar losses of train_IAN.py:169-250,279 as a dict (one device->host copy).  Means are over the GLOBAL batch."""
+        k, n, N = self.k, self.n, self.N
+        s = self.scalars
+        s.zero_()
+        k.sum_rows(self.EX["loss"], n, 4, 1.0 / N, s[0:4])      # [0] discrim_d_loss, [2] acc(p_X)
+        k.sum_rows(self.EH["loss"], n, 4, 1.0 / N, s[4:8])      # [4] gen_recon_loss, [5] CE(p_X_hat,p2), [6] acc
+        k.sum_rows(self.EG["loss"], n, 4, 1.0 / N, s[8:12])     # [8] gen_sample_loss, [9] CE(p_X_gen,p3), [10] acc
+        k.sum_rows(self.ZS["kl"], n * 100, 1, -0.5 / (N * 100.0), s[12:13])
+        k.pair_loss(self.DZ["xhat"], self.X, None, n * 3 * 4096, 1, 1, 0, 0.0, 0, self.ws_loss, 1024, 1.0 / (N * 3 * 4096.0), s[16:18])
+        for i, w in enumerate(ENC_WIDTHS):
+            cnt = (32 >> i) ** 2 * w
+            k.pair_loss(self.EH["a%d" % (i + 1)], self.EX["a%d" % (i + 1)], None, n * cnt, 1, 1, 1, 0.0, 0, self.ws_loss, 1024,
+                        1.0 / (N * cnt * 4.0), s[20 + 2 * i:22 + 2 * i])
+        if self.comm.world > 1:
+            self.comm.all_reduce_sum(s)
+        v = s.cpu().numpy()
+        m = {"discrim_d_loss": v[0], "gen_recon_loss": v[4], "gen_sample_loss": v[8], "discrim_g_loss": v[5] + v[9],
+             "discrim_acc": (v[2] + v[6] + v[10]) / 3.0, "kl_div": v[12], "pixel_loss": v[16], "pixel_acc": 1.0 - v[17],
+             "feature_loss": v[20] + v[22] + v[24] + v[26]}
+        return {kk: float(vv) for kk, vv in m.items()}
+
+    def backward(self, which):
+        """Gradients of the update rules of train_IAN.py:253-273 for ``which`` in {'gen', 'discrim'} (Z_params always)."""
+        k, n, N, c = self.k, self.n, self.N, self.cfg
+        self.touched = set()
+        EX, EH, EG, DZ, DG, ZS = self.EX, self.EH, self.EG, self.DZ, self.DG, self.ZS
+        gen = which == "gen"
+        # ---- shared generator-side loss S = adv_gen + recon_weight*pixel + feature_weight*feature -----------------
+        for i, w in enumerate(ENC_WIDTHS):                                                     # feature_loss seeds (:244)
+            cnt = (32 >> i) ** 2 * w
+            k.pair_loss(EH["a%d" % (i + 1)], EX["a%d" % (i + 1)], EH["da%d" % (i + 1)], n * cnt, 1, 1, 1,
+                        c["feature_weight"] / (4.0 * N * cnt), 0, self.ws_loss, 1024, 0.0, self.scalars[40:42])
+        self.enc_backward(EH, (0, c["agr_weight"] / N, -1, 0.0), True, False, True)            # gen_recon_loss (:247)
+        k.pair_loss(DZ["xhat"], self.X, DZ["dxhat"], n * 3 * 4096, 1, 1, 0, c["recon_weight"] / (N * 3 * 4096.0), 0, self.ws_loss, 1024,
+                    0.0, self.scalars[40:42])                                                  # pixel_loss (:169)
+        k.nhwc_to_nchw(EH["dx"], 32, DZ["tmp_img"], n, 4096, 3)
+        k.axpy(1.0, DZ["tmp_img"], DZ["dxhat"], DZ["dxhat"].numel(), 1)
+        self.dec_backward(DZ, ZS["z"], gen, True)
+        ZS["dz"] = DZ["dz"]
+        self.z_backward(ZS, EX["a4"])
+        if gen:
+            self.enc_backward(EG, (0, c["ags_weight"] / N, -1, 0.0), False, False, True)       # gen_sample_loss (:248)
+            k.nhwc_to_nchw(EG["dx"], 32, DG["dxhat"], n, 4096, 3)
+            self.dec_backward(DG, self.zgen, True, False)
+        else:
+            # ---- discriminator loss, X_hat and X_gen constant (consider_constant, :253) --------------------------
+            self.enc_backward(EX, (0, c["dd_weight"] / N, -1, 0.0), False, True, False)        # discrim_d_loss (:234)
+            self.enc_backward(EH, (1, c["dg_weight"] / N, -1, 0.0), False, True, False)        # p_X_hat vs p2 (:228)
+            self.enc_backward(EG, (2, c["dg_weight"] / N, -1, 0.0), False, True, False)        # p_X_gen vs p3
+
+    def _regularizers(self, which):
+        """train_IAN.py:211-221: L2 on the Z parameters, orthogonal penalty on the 4-D weights of the updated group."""
+        k, c = self.k, self.cfg
+        for nme in self.groups["Z"].names:
+            if not nme.endswith(".beta"):
+                k.axpy(2.0 * c["reg"], self.P(nme), self.G(nme), self.P(nme).numel(), 1)
+        if "ortho" not in c:
+            return
+        grp = self.groups["dec" if which == "gen" else "enc"]
+        for nme in grp.names:
+            o, cnt, shape = grp.offsets[nme]
+            if nme[-1] == "W" and len(shape) == 4:
+                k.ortho(self.P(nme), self.G(nme), shape[0], shape[1], shape[2], float(c["ortho"]), self.tmp_vals)
+
+    def _adam(self, gname):
+        g = self.groups[gname]
+        g.t += 1
+        b1, b2 = float(self.cfg["beta1"]), 0.999
+        a_t = self.lr * math.sqrt(1.0 - b2 ** g.t) / (1.0 - b1 ** g.t)
+        self.k.adam(g.p, g.g, g.m, g.v, g.numel, a_t, b1, b2, 1e-8)
+
+    def step(self, which, X, Z, eps, return_metrics=True):
+        upd = "dec" if which == "gen" else "enc"
+        self.forward(X, Z, eps)
+        m = self.metrics() if return_metrics else None
+        self.backward(which)
+        if self.comm.world > 1:
+            self.torch.cuda.current_stream().synchronize()
+            for gname in (upd, "Z"):
+                self.comm.all_reduce_buckets(self.groups[gname].g)
+        self._regularizers(which)
+        self._adam(upd)
+        self._adam("Z")
+        return m
+
+    def update_gen(self, X, Z, eps):
+        """train_IAN.py:309-318 -> [gen_recon_loss, gen_sample_loss, pixel_loss, feature_loss, pixel_acc]"""
+        m = self.step("gen", X, Z, eps)
+        return [m[k] for k in ("gen_recon_loss", "gen_sample_loss", "pixel_loss", "feature_loss", "pixel_acc")]
+
+    def update_discrim(self, X, Z, eps):
+        """train_IAN.py:320-329 -> [discrim_g_loss, discrim_d_loss, discrim_acc, pixel_loss, pixel_acc]"""
+        m = self.step("discrim", X, Z, eps)
+        return [m[k] for k in ("discrim_g_loss", "discrim_d_loss", "discrim_acc", "pixel_loss", "pixel_acc")]
+
+    # ---- introspection for tests / checkpoints ----------------------------------------------------------
+    def grads_numpy(self, gname):
+        g = self.groups[gname]
+        flat = g.g.cpu().numpy()
+        return {n: flat[o:o + cnt].reshape(shape).copy() for n, (o, cnt, shape) in g.offsets.items()}
+
+    def params_numpy(self):
+        out = {}
+        for g in self.groups.values():
+            flat = g.p.cpu().numpy()
+            for n, (o, cnt, shape) in g.offsets.items():
+                out[n] = flat[o:o + cnt].reshape(shape).copy()
+        return out

@@ -1,0 +1,305 @@
+"""GPU unit parity of the training building blocks (include/ian_train.h) against float64 torch-CPU autograd:
+ian_layer_{forward,backward_data,backward_weight} for every layer kind, and the batch-norm / MinibatchLayer /
+IAF / loss / regulariser / Adam kernels."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(np.asarray(b)).max() + 1e-30))
+
+
+def cs(c):
+    return (c + 31) // 32 * 32
+
+
+def to_nhwc(x, stride=None):
+    """(n,c,h,w) numpy -> cuda tensor (n,h,w,stride) zero padded"""
+    n, c, h, w = x.shape
+    s = stride or cs(c)
+    out = np.zeros((n, h, w, s), np.float32)
+    out[..., :c] = x.transpose(0, 2, 3, 1)
+    return torch.from_numpy(out).cuda()
+
+
+def from_nhwc(t, c):
+    return t.cpu().numpy()[..., :c].transpose(0, 3, 1, 2)
+
+
+@pytest.fixture(scope="module")
+def env():
+    from neural_photo_editor_amd.lib import load_train_library
+    from neural_photo_editor_amd import trainer as T
+    lib = load_train_library()
+    return lib, T, T.K(lib)
+
+
+def dparams(shapes):
+    return [torch.zeros(int(np.prod(s)), device="cuda") for s in shapes]
+
+
+CASES = [
+    ("conv", dict(cin=32, cout=64, h=16)), ("conv", dict(cin=3, cout=32, h=32)), ("conv", dict(cin=64, cout=160, h=8)),
+    ("deconv", dict(cin=64, cout=32, h=8)), ("deconv", dict(cin=32, cout=160, h=4)),
+    ("mdc", dict(cin=32, cout=32, h=16, scales=[0, 2])), ("mdc", dict(cin=64, cout=64, h=8, scales=[0, 2, 3])),
+    ("mdc", dict(cin=32, cout=2, h=32, scales=[2, 3, 4])), ("mdc", dict(cin=2, cout=2, h=32, scales=[2, 3, 4])),
+    ("mdc", dict(cin=4, cout=2, h=32, scales=[2, 3, 4])),
+]
+
+
+@pytest.mark.parametrize("kind,g", CASES)
+@pytest.mark.parametrize("n", [3, 8])
+def test_spatial_layers(env, kind, g, n):
+    lib, T, k = env
+    rs = np.random.RandomState(hash((kind, g["cin"], g["cout"], n)) % 2 ** 31)
+    cin, cout, h = g["cin"], g["cout"], g["h"]
+    x = rs.randn(n, cin, h, h).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    if kind == "conv":
+        W = (rs.randn(cout, cin, 5, 5) * 0.1).astype(np.float32)
+        params = [torch.tensor(W, dtype=torch.float64, requires_grad=True)]
+        y = F.conv2d(xt, params[0], stride=2, padding=2)
+        layer = T.Layer(lib, T.K_CONV, cin, cout, h, h)
+    elif kind == "deconv":
+        W = (rs.randn(cin, cout, 5, 5) * 0.1).astype(np.float32)
+        params = [torch.tensor(W, dtype=torch.float64, requires_grad=True)]
+        y = F.conv_transpose2d(xt, torch.flip(params[0], (2, 3)), stride=2, padding=2, output_padding=1)
+        layer = T.Layer(lib, T.K_DECONV, cin, cout, h, h)
+    else:
+        sc = g["scales"]
+        W = (rs.randn(cout, cin, 3, 3) * 0.2).astype(np.float32)
+        coeffs = [rs.uniform(0.5, 1.5, cout).astype(np.float32) for _ in range(1 + len(sc))]
+        params = [torch.tensor(W, dtype=torch.float64, requires_grad=True)] + [torch.tensor(c, dtype=torch.float64, requires_grad=True) for c in coeffs]
+        y = F.conv2d(xt, params[0], padding=1) * params[1].reshape(1, -1, 1, 1)
+        for i, s in enumerate(sc):
+            cf = params[2 + i].reshape(1, -1, 1, 1)
+            if s == 0:
+                y = y + F.conv2d(xt, params[0].mean((2, 3), keepdim=True)) * cf
+            else:
+                y = y + F.conv2d(xt, params[0], padding=s, dilation=s) * cf
+        layer = T.Layer(lib, T.K_MDC, cin, cout, h, h, scales=sc)
+    dy = rs.randn(*y.shape).astype(np.float32)
+    gx, *gp = torch.autograd.grad(y, [xt] + params, torch.tensor(dy, dtype=torch.float64))
+    dev_params = [torch.from_numpy(p.detach().numpy().astype(np.float32).ravel()).cuda() for p in params]
+    layer.set_params(dev_params)
+    oh = y.shape[2]
+    xd, dyd = to_nhwc(x), to_nhwc(dy)
+    yd = torch.zeros(n, oh, oh, cs(cout), device="cuda")
+    layer.forward(xd, n, yd)
+    assert rel(from_nhwc(yd, cout), y.detach().numpy()) < TOL
+    dxd = torch.zeros(n, h, h, cs(cin), device="cuda")
+    layer.backward_data(dyd, n, dxd)
+    assert rel(from_nhwc(dxd, cin), gx.numpy()) < TOL
+    layer.backward_data(dyd, n, dxd, accumulate=True)
+    assert rel(from_nhwc(dxd, cin), 2 * gx.numpy()) < TOL
+    dp = dparams([p.shape for p in params])
+    layer.backward_weight(xd, dyd, n, dp)
+    for got, ref in zip(dp, gp):
+        assert rel(got.cpu().numpy().reshape(ref.shape), ref.numpy()) < TOL
+    layer.backward_weight(xd, dyd, n, dp, accumulate=True)
+    assert rel(dp[0].cpu().numpy().reshape(gp[0].shape), 2 * gp[0].numpy()) < TOL
+    layer.close()
+
+
+@pytest.mark.parametrize("fin,fout,flat,unflat", [(1000, 100, None, None), (256 * 16, 200, (256, 4, 4), None), (100, 64 * 16, None, (64, 4, 4)),
+                                                  (1024, 2500, None, None)])
+def test_dense_layers(env, fin, fout, flat, unflat):
+    lib, T, k = env
+    n = 5
+    rs = np.random.RandomState(fin + fout)
+    W = (rs.randn(fin, fout) * 0.05).astype(np.float32)
+    x = rs.randn(n, fin).astype(np.float32)
+    dy = rs.randn(n, fout).astype(np.float32)
+    layer = T.Layer(lib, T.K_DENSE, fin, fout, flat=flat or (0, 0, 0), unflat=unflat or (0, 0, 0))
+    layer.set_params([torch.from_numpy(W.ravel()).cuda()])
+    # reference-order vectors <-> internal (H,W,C) order of flattened maps (App. B.6)
+    def to_internal(v, chw):
+        if chw is None:
+            out = np.zeros((v.shape[0], cs(v.shape[1])), np.float32); out[:, :v.shape[1]] = v; return out
+        c, h, w = chw
+        return v.reshape(-1, c, h, w).transpose(0, 2, 3, 1).reshape(v.shape[0], -1).copy()
+    def from_internal(t, width, chw):
+        a = t.cpu().numpy()
+        if chw is None:
+            return a[:, :width]
+        c, h, w = chw
+        return a.reshape(-1, h, w, c).transpose(0, 3, 1, 2).reshape(a.shape[0], -1)
+    xd = torch.from_numpy(to_internal(x, flat)).cuda()
+    dyd = torch.from_numpy(to_internal(dy, unflat)).cuda()
+    ystride = dyd.shape[1]
+    yd = torch.zeros(n, ystride, device="cuda")
+    layer.forward(xd, n, yd, y_stride=ystride)
+    assert rel(from_internal(yd, fout, unflat), x.astype(np.float64) @ W) < TOL
+    dxd = torch.zeros_like(xd)
+    layer.backward_data(dyd, n, dxd, dx_stride=xd.shape[1])
+    assert rel(from_internal(dxd, fin, flat), dy.astype(np.float64) @ W.T) < TOL
+    dW = torch.zeros(fin * fout, device="cuda")
+    layer.backward_weight(xd, dyd, n, [dW])
+    assert rel(dW.cpu().numpy().reshape(fin, fout), x.astype(np.float64).T @ dy) < TOL
+    layer.close()
+
+
+@pytest.mark.parametrize("rows,C,act", [(4 * 16, 32, 2), (3 * 64, 128, 2), (5, 1000, 1), (4, 100, 0)])
+def test_batchnorm_train_forward_backward(env, rows, C, act):
+    lib, T, k = env
+    rs = np.random.RandomState(rows + C)
+    stride = cs(C)
+    y = (rs.randn(rows, C) * 2 + 0.5).astype(np.float32)
+    gamma, beta = rs.uniform(0.5, 1.5, C).astype(np.float32), rs.randn(C).astype(np.float32)
+    dA = rs.randn(rows, C).astype(np.float32)
+    yt = torch.tensor(y, dtype=torch.float64, requires_grad=True)
+    gt, bt = torch.tensor(gamma, dtype=torch.float64, requires_grad=True), torch.tensor(beta, dtype=torch.float64, requires_grad=True)
+    mean, var = yt.mean(0), ((yt - yt.mean(0)) ** 2).mean(0)
+    pre = (yt - mean) / torch.sqrt(var + 1e-4) * gt + bt
+    a = {0: pre, 1: torch.relu(pre), 2: F.leaky_relu(pre, 0.2)}[act]
+    gy, gg, gb = torch.autograd.grad(a, [yt, gt, bt], torch.tensor(dA, dtype=torch.float64))
+    pad = lambda v: torch.from_numpy(np.pad(v, ((0, 0), (0, stride - C)))).cuda()
+    yd, dAd = pad(y), pad(dA)
+    ad = torch.zeros_like(yd)
+    bn = T.BN(torch, C, "cuda")
+    ws = torch.zeros(256 * 2 * C, device="cuda")
+    k.colstats(0, yd, None, None, None, None, rows, C, stride, 0, ws, min(256, rows), bn.sums)
+    k.bn_make_affine(bn.sums, float(rows), 1e-4, torch.from_numpy(gamma).cuda(), torch.from_numpy(beta).cuda(), C, bn.mean, bn.inv_std, bn.scale, bn.shift)
+    k.affine(yd, ad, bn.scale, bn.shift, rows, C, stride, act)
+    assert rel(ad.cpu().numpy()[:, :C], a.detach().numpy()) < TOL
+    k.colstats(1, dAd, ad, yd, bn.mean, bn.inv_std, rows, C, stride, act, ws, min(256, rows), bn.bsums)
+    dyd = torch.zeros_like(yd)
+    k.bn_bwd(dAd, ad, yd, bn.mean, bn.inv_std, bn.scale, bn.bsums, float(rows), dyd, rows, C, stride, act)
+    s = bn.bsums.cpu().numpy()
+    assert rel(s[:C], gb.numpy()) < 1e-4 and rel(s[C:], gg.numpy()) < 1e-4
+    assert rel(dyd.cpu().numpy()[:, :C], gy.numpy()) < 1e-4
+
+
+def test_minibatch_layer_and_head(env):
+    lib, T, k = env
+    n, nin, nk, nd = 6, 64, 20, 5
+    rs = np.random.RandomState(0)
+    theta = (rs.randn(nin, nk, nd) * 0.05).astype(np.float32)
+    lws = (rs.randn(nk, nd) * 0.1).astype(np.float32)
+    b = rs.randn(nk).astype(np.float32)
+    feat = rs.randn(n, nin).astype(np.float32)
+    Wd = (rs.randn(nin + nk, 3) * 0.3).astype(np.float32)
+    tt = lambda v: torch.tensor(v, dtype=torch.float64, requires_grad=True)
+    th, lw, bb, ft, wd = tt(theta), tt(lws), tt(b), tt(feat), tt(Wd)
+    W = th * (torch.exp(lw) / torch.sqrt((th ** 2).sum(0))).unsqueeze(0)
+    act = torch.tensordot(ft, W, dims=([1], [0]))
+    ad = (act.unsqueeze(3) - act.permute(1, 2, 0).unsqueeze(0)).abs().sum(2) + 1e6 * torch.eye(n, dtype=torch.float64).unsqueeze(1)
+    f = torch.exp(-ad).sum(2) + bb.unsqueeze(0)
+    mb = torch.cat([ft, f], 1)
+    p = torch.softmax(mb @ wd, 1)
+    loss = 0.7 * (-torch.log(p[:, 1])).sum() + 0.2 * (-torch.log(p[:, 2])).sum()
+    gth, glw, gbb, gft, gwd = torch.autograd.grad(loss, [th, lw, bb, ft, wd])
+    c = lambda v: torch.from_numpy(np.ascontiguousarray(v, np.float32)).cuda()
+    ncol = nk * nd
+    Wdev, colscale = torch.zeros(nin * ncol, device="cuda"), torch.zeros(ncol, device="cuda")
+    k.mb_weight(c(theta), c(lws), Wdev, colscale, nin, ncol)
+    assert rel(Wdev.cpu().numpy().reshape(nin, nk, nd), W.detach().numpy()) < TOL
+    layer = T.Layer(lib, T.K_DENSE, nin, ncol)
+    layer.set_params([Wdev])
+    featd = c(feat)
+    sa, sm = cs(ncol), cs(nin + nk)
+    actd = torch.zeros(n, sa, device="cuda")
+    layer.forward(featd, n, actd, y_stride=sa)
+    mbd = torch.zeros(n, sm, device="cuda")
+    k.mb_forward(actd, n, sa, 0, n, nk, nd, c(b), featd, nin, nin, mbd, sm)
+    assert rel(mbd.cpu().numpy()[:, :nin + nk], mb.detach().numpy()) < TOL
+    pd, ld = torch.zeros(n, 3, device="cuda"), torch.zeros(n, 4, device="cuda")
+    k.disc_head(mbd, sm, nin + nk, c(Wd), n, 1, 2, 1, pd, ld)
+    assert rel(pd.cpu().numpy(), p.detach().numpy()) < TOL
+    assert rel(ld.cpu().numpy()[:, 0], -np.log(p.detach().numpy()[:, 1])) < TOL
+    dlog, dmb = torch.zeros(n, 4, device="cuda"), torch.zeros(n, sm, device="cuda")
+    k.disc_head_bwd(pd, c(Wd), nin + nk, n, 1, 0.7, 2, 0.2, dlog, dmb, sm)
+    dWd = torch.zeros((nin + nk) * 3, device="cuda")
+    k.disc_head_wgrad(mbd, sm, nin + nk, n, dlog, dWd, 0)
+    assert rel(dWd.cpu().numpy().reshape(-1, 3), gwd.numpy()) < 1e-4
+    dact = torch.zeros(n, sa, device="cuda")
+    k.mb_backward(actd, n, sa, 0, n, nk, nd, dmb.view(-1)[nin:], sm, dact, sa)
+    dfeat = torch.zeros(n, nin, device="cuda")
+    k.grad_pass(dmb, sm, 0, dfeat, None, nin, n, nin, 0, 0)
+    layer.backward_data(dact, n, dfeat, dx_stride=nin, accumulate=True)
+    assert rel(dfeat.cpu().numpy(), gft.numpy()) < 1e-4
+    dW = torch.zeros(nin * ncol, device="cuda")
+    layer.backward_weight(featd, dact, n, [dW])
+    dth, dlw = torch.zeros(nin * ncol, device="cuda"), torch.zeros(ncol, device="cuda")
+    k.mb_weight_bwd(c(theta), colscale, dW, dth, dlw, nin, ncol, 0)
+    assert rel(dth.cpu().numpy().reshape(theta.shape), gth.numpy()) < 1e-4
+    assert rel(dlw.cpu().numpy().reshape(lws.shape), glw.numpy()) < 1e-4
+    layer.close()
+
+
+def test_sampling_iaf_losses_ortho_adam(env):
+    lib, T, k = env
+    from neural_photo_editor_amd import made
+    n, d = 5, 100
+    rs = np.random.RandomState(3)
+    c = lambda v: torch.from_numpy(np.ascontiguousarray(v, np.float32)).cuda()
+    tt = lambda v: torch.tensor(v, dtype=torch.float64, requires_grad=True)
+    pad = lambda v: np.pad(v, ((0, 0), (0, 128 - d))).astype(np.float32)
+    mu, ls, eps = rs.randn(n, d).astype(np.float32), (rs.randn(n, d) * 0.3).astype(np.float32), rs.randn(n, d).astype(np.float32)
+    masks = made.masks_once(d)
+    Ws = [(rs.randn(d, d) * 0.1).astype(np.float32) * m for _ in range(2) for m in masks]
+    bs = [(rs.randn(d) * 0.1).astype(np.float32) for _ in range(6)]
+    mut, lst = tt(mu), tt(ls)
+    z0 = mut + torch.exp(lst) * torch.tensor(eps, dtype=torch.float64)
+    W = [torch.tensor(w, dtype=torch.float64) for w in Ws]
+    Bv = [torch.tensor(b, dtype=torch.float64) for b in bs]
+    mm = lambda z, o: (torch.relu(z @ W[o] + Bv[o]) @ W[o + 1] + Bv[o + 1]) + (z @ W[o + 2] + Bv[o + 2])
+    z = (z0 - mm(z0, 0)) / torch.exp(mm(z0, 3))
+    dz = rs.randn(n, d).astype(np.float32)
+    kl = -0.5 * (1 + 2 * lst - mut ** 2 - torch.exp(2 * lst)).mean()
+    gmu, gls = torch.autograd.grad((z * torch.tensor(dz, dtype=torch.float64)).sum() + kl, [mut, lst])
+    wts, bias = c(np.stack(Ws)), c(np.stack(bs))
+    mud, lsd, epsd = c(pad(mu)), c(pad(ls)), c(eps)
+    z0d, zd, klt = torch.zeros(n, 128, device="cuda"), torch.zeros(n, 128, device="cuda"), torch.zeros(n, d, device="cuda")
+    k.sample(mud, lsd, epsd, z0d, klt, n, d, 128, d)
+    k.made_iaf(z0d, zd, wts, bias, n, d, 128)
+    assert rel(zd.cpu().numpy()[:, :d], z.detach().numpy()) < TOL
+    out = torch.zeros(4, device="cuda")
+    k.sum_rows(klt, n * d, 1, -0.5 / (n * d), out)
+    assert abs(float(out[0]) - float(kl)) < 1e-5
+    dz0d, dmud, dlsd = torch.zeros(n, 128, device="cuda"), torch.zeros(n, 128, device="cuda"), torch.zeros(n, 128, device="cuda")
+    k.made_iaf_bwd(z0d, c(pad(dz)), dz0d, wts, bias, n, d, 128)
+    k.sample_bwd(mud, lsd, epsd, dz0d, dmud, dlsd, n, d, 128, d, 1.0 / (n * d))
+    assert rel(dmud.cpu().numpy()[:, :d], gmu.numpy()) < 1e-4 and rel(dlsd.cpu().numpy()[:, :d], gls.numpy()) < 1e-4
+    # pixel loss / feature loss
+    a, b = rs.uniform(-1, 1, (7, 33)).astype(np.float32), rs.uniform(-1, 1, (7, 33)).astype(np.float32)
+    at = tt(a)
+    pl = (2 * (at - torch.tensor(b, dtype=torch.float64) + 1e-8).abs()).mean()
+    (ga,) = torch.autograd.grad(3.0 * pl, [at])
+    ws, da = torch.zeros(2048, device="cuda"), torch.zeros(7 * 33, device="cuda")
+    k.pair_loss(c(a), c(b), da, 7 * 33, 1, 1, 0, 3.0 / (7 * 33), 0, ws, 64, 1.0 / (7 * 33), out)
+    assert abs(float(out[0]) - float(pl)) < 1e-5 and rel(da.cpu().numpy().reshape(7, 33), ga.numpy()) < TOL
+    ml = ((at - torch.tensor(b, dtype=torch.float64)) ** 2).mean()
+    (ga,) = torch.autograd.grad(ml, [at])
+    k.pair_loss(c(a), c(b), da, 7 * 33, 1, 1, 1, 1.0 / (7 * 33), 0, ws, 64, 1.0 / (7 * 33), out)
+    assert abs(float(out[0]) - float(ml)) < 1e-5 and rel(da.cpu().numpy().reshape(7, 33), ga.numpy()) < TOL
+    # orthogonal regulariser
+    for shape in ((6, 40, 5, 5), (9, 300, 3, 3)):
+        Wn = (rs.randn(*shape) * 0.1).astype(np.float32)
+        wt = tt(Wn)
+        y = torch.einsum("abik,abjk->aij", wt, wt) - torch.eye(shape[2], dtype=torch.float64).unsqueeze(0)
+        val = y.abs().sum()
+        (gw,) = torch.autograd.grad(1e-3 * val, [wt])
+        dW, vals = torch.zeros(Wn.size, device="cuda"), torch.zeros(64, device="cuda")
+        k.ortho(c(Wn), dW, shape[0], shape[1], shape[2], 1e-3, vals)
+        assert abs(float(vals[:shape[0]].sum()) - float(val)) < 1e-3 * float(val)
+        assert rel(dW.cpu().numpy().reshape(shape), gw.numpy()) < 1e-4
+    # Adam (App. B.7)
+    p, g = rs.randn(1000).astype(np.float32), rs.randn(1000).astype(np.float32)
+    m, v = np.zeros(1000, np.float32), np.zeros(1000, np.float32)
+    pd_, md, vd = c(p), c(m), c(v)
+    pr = p.astype(np.float64)
+    mr, vr = np.zeros(1000), np.zeros(1000)
+    for t in (1, 2, 3):
+        a_t = 2e-4 * np.sqrt(1 - 0.999 ** t) / (1 - 0.5 ** t)
+        k.adam(pd_, c(g), md, vd, 1000, float(a_t), 0.5, 0.999, 1e-8)
+        mr = 0.5 * mr + 0.5 * g
+        vr = 0.999 * vr + 0.001 * g.astype(np.float64) ** 2
+        pr = pr - a_t * mr / (np.sqrt(vr) + 1e-8)
+    assert np.abs(pd_.cpu().numpy() - pr).max() < 1e-6

@@ -167,3 +167,21 @@ def test_missing_parameter_is_an_error_in_the_c_layer():
     with pytest.raises(L.IanError):
         h.finalize()   # either "no HIP device" (CPU box) or "missing parameter" (GPU box): never a silent success
     h.close()
+
+
+def test_training_abi_exports_every_header_symbol():
+    """include/ian_train.h: every declared entry point resolves in libian.so and gets its prototype from the header."""
+    lib = L.load_train_library()
+    names = L.train_exports()
+    assert len(names) >= 39 and "ian_layer_backward_weight" in names and "ian_k_adam" in names
+    for n in names:
+        assert getattr(lib, n).argtypes is not None
+
+
+def test_layer_creation_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from neural_photo_editor_amd.trainer import Layer, IanTrainError
+    with pytest.raises(IanTrainError, match="no HIP device"):
+        Layer(L.load_train_library(), 4, 128, 64)
