@@ -58,6 +58,53 @@ def cpu_baseline(arch, P, batch, budget_s=20.0):
             "sample": "%d passes of batch %d through the torch-CPU restatement (not Theano), %s" % (n, batch, model)}
 
 
+def pmc_traffic(arch, B):
+    """HBM bytes per tapgemm launch from the committed rocprofv3 PMC passes of this same command (profiles/, made by
+    scripts/profile_round.sh + scripts/summarize_profile.py; FETCH_SIZE x2-corrected per MI355X_MICROARCH.md).
+    PMC counters cannot be read from inside the process, so the latest committed summary is quoted; None if absent."""
+    import glob
+    tag = "ian_simple_b64" if (arch, B) == ("IAN_simple", 64) else ("ian_b256" if (arch, B) == ("IAN", 256) else None)
+    if tag is None:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s.json" % tag)))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as fh:
+            v = json.load(fh).get("tapgemm_traffic_bytes_per_launch")
+        return (float(v) if v else None), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
+def train_step_bench(batch, rank, world, iters=3):
+    """ms per update_gen / update_discrim (train_IAN.py:309-329) of the full IAN at `batch` images per GPU."""
+    import torch
+    from neural_photo_editor_amd.trainer import Trainer, Comm
+    from oracle import ian_oracle as O           # synthetic parameter generator only
+    from oracle.train_twin import make_train_params
+    P = make_train_params(O.make_params("IAN", 1))
+    tr = Trainer(os.path.join(ROOT, "neural_photo_editor_amd", "configs", "IAN.py"), P, batch=batch, comm=Comm(), exact=True)
+    rs = np.random.RandomState(50 + rank)
+    X = torch.from_numpy(O.make_images(batch, seed=200 + rank)).cuda()
+    Z = torch.from_numpy(rs.randn(batch, 100).astype(np.float32)).cuda()
+    eps = torch.from_numpy(rs.randn(batch, 100).astype(np.float32)).cuda()
+    out = {}
+    for which in ("gen", "discrim"):
+        tr.step(which, X, Z, eps, return_metrics=False)          # warm-up (schedules, workspaces)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(iters):
+            tr.step(which, X, Z, eps, return_metrics=False)
+        torch.cuda.synchronize()
+        out["update_%s_ms" % which] = (time.perf_counter() - t) / iters * 1e3
+    pair = out["update_gen_ms"] + out["update_discrim_ms"]
+    out.update({"images_per_s": 2 * batch * world / (pair * 1e-3), "per_gpu_batch": batch, "global_batch": batch * world,
+                "parallelism": "dp%d, RCCL all-reduce of flat gradient groups, SyncBN statistics + MinibatchLayer all-gather (exact)" % world,
+                "note": "one update_gen + one update_discrim (strict alternation, train_IAN.py:497-504) over synthetic data"})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +114,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 64 for IAN_simple, 256 for IAN)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-edit", action="store_true")
+    ap.add_argument("--train", action="store_true", help="also time the train_IAN.py step (default: only on 1 GPU)")
+    ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--train-batch", type=int, default=128, help="per-GPU minibatch of the training step (config 5: 1024 over 8 GPUs)")
+    ap.add_argument("--host-io", action="store_true", help="also time the API.py-style call: host numpy in, host numpy out (PCIe inclusive)")
     args = ap.parse_args()
 
     import torch
@@ -135,9 +186,11 @@ def main():
         flops_per_launch = pr["tapgemm_flops"] / launches
         avg_ms = pr["tapgemm_ms"] / launches
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(arch, B)
         roofline = {"bound": "mfma", "kernel": "tapgemm_kernel (fp32 v_mfma_f32_32x32x2_f32)", "achieved": achieved,
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                    "traffic": None, "launches_per_step": launches / min(args.steps, 20),
+                    "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % traffic_src if traffic else None,
+                    "flop_per_launch": flops_per_launch, "launches_per_step": launches / min(args.steps, 20),
                     "avg_launch_ms": avg_ms, "tapgemm_share_of_step": pr["tapgemm_ms"] / max(pr["total_ms"], 1e-9),
                     "whole_step_tflops": FLOP_PER_RECON[arch] * B / (ms_per_step * 1e-3) / 1e12}
         edit = None
@@ -156,8 +209,30 @@ def main():
                 model.sample_at(z)
                 lat.append((time.perf_counter() - t) * 1e3)
             lat = np.array(lat[20:])
+            os.environ["IAN_NO_DEC_CACHE"] = "1"   # every call recomputes the decoder forward (2 fwd + 1 bwd per step)
+            lat2 = []
+            for i in range(60):
+                t = time.perf_counter()
+                g = model.imgradRGB(c1, r1, c2, r2, rgb, z)
+                z = z - 0.05 * g * (1 + (c2 - c1))
+                model.sample_at(z)
+                lat2.append((time.perf_counter() - t) * 1e3)
+            del os.environ["IAN_NO_DEC_CACHE"]
             edit = {"p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)), "steps": len(lat),
-                    "update": "gradient descent (reference, NPE.py:199-209)", "includes": "host<->device copies of z, rgb, image"}
+                    "p50_ms_no_forward_cache": float(np.percentile(lat2[10:], 50)),
+                    "update": "gradient descent (reference, NPE.py:199-209)",
+                    "calls": "imgradRGB + sample_at through the API.py surface (host numpy in/out); imgradRGB reuses the "
+                             "decoder activations sample_at left for the same latent",
+                    "includes": "host<->device copies of z, rgb, image"}
+        host_io = None
+        if args.host_io:
+            xh = x.cpu().numpy()
+            model.reconstruct(xh)
+            t = time.perf_counter()
+            for _ in range(10):
+                model.reconstruct(xh)
+            host_io = {"value": 10 * B / (time.perf_counter() - t), "unit": "reconstructions/s",
+                       "note": "host numpy in -> host numpy out per call (pageable memory, PCIe inclusive); never `value`"}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(arch, P, B if arch == "IAN_simple" else 32)
@@ -169,6 +244,17 @@ def main():
                                    % (arch, B), "parallelism": "replicas x%d (no data-path collective)" % world},
             "roofline": roofline, "cpu_baseline": cpu, "edit_step": edit,
         }
+        if host_io:
+            result["host_io"] = host_io
+    # ---- train_IAN.py step (BASELINE.json configs[4]): full IAN, data parallel, RCCL gradient all-reduce ----------
+    train = None
+    if (args.train or world == 1) and not args.no_train:
+        try:
+            train = train_step_bench(args.train_batch, rank, world)
+        except Exception as exc:  # never let the secondary measurement take the headline number down
+            train = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if rank == 0 and result is not None:
+        result["train_step"] = train
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -130,6 +130,11 @@ struct ian_handle {
   size_t stage_out_cap = 0;
   float* d_gseed = nullptr;  // 3*H*W gradient seed
   float* d_rgb = nullptr;
+  // decoder-forward cache for the interactive loop (NPE.py:205,218: imgradRGB(z) right after sample_at(z)):
+  // the batch-1 decoder activations of the last HOST latent are kept; a gradient call on the same latent skips
+  // its forward pass.  Any other use of the decoder slots invalidates it.
+  std::vector<float> dec_cache_z;
+  bool dec_cache_valid = false;
   // profiling
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -1172,8 +1177,18 @@ int grad_common(ian_handle* h, int mode, int c1, int r1, int c2, int r2, const f
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   TotalTimer tt(h, st);
-  if ((rc = set_latent_input(h, h->desc.z_slot, z, 1, st))) return rc;
-  if ((rc = run_segment(h, IAN_SEG_DEC, 1, st))) return rc;
+  const bool host_z = !is_device_ptr(z);
+  const bool hit = h->dec_cache_valid && host_z && getenv("IAN_NO_DEC_CACHE") == nullptr &&
+                   memcmp(h->dec_cache_z.data(), z, sizeof(float) * h->desc.num_latents) == 0;
+  if (!hit) {
+    h->dec_cache_valid = false;
+    if ((rc = set_latent_input(h, h->desc.z_slot, z, 1, st))) return rc;
+    if ((rc = run_segment(h, IAN_SEG_DEC, 1, st))) return rc;
+    if (host_z) {
+      h->dec_cache_z.assign(z, z + h->desc.num_latents);
+      h->dec_cache_valid = true;
+    }
+  }
   const float* d_rgb = nullptr;
   if (mode == 1) {
     Slot& out = h->slots[h->desc.out_slot];
@@ -1333,6 +1348,7 @@ int ian_encode(ian_handle* h, const float* x, int32_t n, float* z, void* stream)
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   TotalTimer tt(h, st);
+  h->dec_cache_valid = false;
   if ((rc = set_image_input(h, x, n, st))) return rc;
   if ((rc = run_segment(h, IAN_SEG_ENC, n, st))) return rc;
   if ((rc = run_segment(h, IAN_SEG_IAF, n, st))) return rc;
@@ -1343,6 +1359,7 @@ int ian_iaf(ian_handle* h, const float* zpre, int32_t n, float* z, void* stream)
   int rc = check_ready(h, n);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  h->dec_cache_valid = false;
   if ((rc = set_latent_input(h, h->desc.zpre_slot, zpre, n, st))) return rc;
   if ((rc = run_segment(h, IAN_SEG_IAF, n, st))) return rc;
   return get_latent_output(h, h->desc.z_slot, z, n, st);
@@ -1353,9 +1370,15 @@ int ian_decode(ian_handle* h, const float* z, int32_t n, float* x, void* stream)
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   TotalTimer tt(h, st);
+  h->dec_cache_valid = false;
   if ((rc = set_latent_input(h, h->desc.z_slot, z, n, st))) return rc;
   if ((rc = run_segment(h, IAN_SEG_DEC, n, st))) return rc;
-  return get_image_output(h, x, n, st);
+  if ((rc = get_image_output(h, x, n, st))) return rc;
+  if (n == 1 && !is_device_ptr(z)) {  // remember which latent the resident batch-1 activations belong to
+    h->dec_cache_z.assign(z, z + h->desc.num_latents);
+    h->dec_cache_valid = true;
+  }
+  return 0;
 }
 
 int ian_reconstruct(ian_handle* h, const float* x, int32_t n, float* xhat, void* stream) {
@@ -1363,6 +1386,7 @@ int ian_reconstruct(ian_handle* h, const float* x, int32_t n, float* xhat, void*
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   TotalTimer tt(h, st);
+  h->dec_cache_valid = false;
   if ((rc = set_image_input(h, x, n, st))) return rc;
   if ((rc = run_segment(h, IAN_SEG_ENC, n, st))) return rc;
   if ((rc = run_segment(h, IAN_SEG_IAF, n, st))) return rc;
@@ -1373,6 +1397,7 @@ int ian_reconstruct(ian_handle* h, const float* x, int32_t n, float* xhat, void*
 int ian_autotune(ian_handle* h, int32_t n, int32_t what, void* stream) {
   int rc = check_ready(h, n);
   if (rc) return rc;
+  h->dec_cache_valid = false;
   hipStream_t st = (hipStream_t)stream;
   const bool prof = h->prof;
   h->prof = false;

@@ -643,8 +643,11 @@ class Trainer:
         self.zgen = self.torch.zeros(self.n, 128, dtype=self.torch.float32, device=self.dev)
         self.zgen0 = self.torch.zeros(self.n, 128, dtype=self.torch.float32, device=self.dev)
 
-    def forward(self, X, Z, eps):
-        """The three passes of train_IAN.py:116-149.  X (n,3,64,64), Z (n,100), eps (n,100): device tensors."""
+    def forward(self, X, Z, eps, xhat_override=None, xgen_override=None):
+        """The three passes of train_IAN.py:116-149.  X (n,3,64,64), Z (n,100), eps (n,100): device tensors.
+        ``*_override`` (test hook): images fed to the encoder passes on X_hat / X_gen instead of the decoder outputs
+        (the decoders still run).  The discriminator's |a_b - a_b'| kernels and the leaky-ReLU kinks make the
+        gradients discontinuous in the activations, so a parity test feeds both implementations the SAME images."""
         k, n = self.k, self.n
         self._ensure_passes()
         self.refresh_weights()
@@ -653,11 +656,11 @@ class Trainer:
         self.ZS["eps"] = eps
         self.z_forward(self.ZS, self.EX["a4"], eps)
         self.dec_forward(self.DZ, self.ZS["z"])                                                # X_hat
-        self.enc_forward(self.EH, self.DZ["xhat"], targets=(0, 1), acc_target=1)               # p_X_hat vs p1 (gen) / p2 (discrim)
+        self.enc_forward(self.EH, self.DZ["xhat"] if xhat_override is None else xhat_override, targets=(0, 1), acc_target=1)  # p_X_hat
         k.grad_pass(Z, Z.shape[1], 0, self.zgen0, None, 128, n, 100, 0, 0)                     # (n,100) -> padded rows
         k.made_iaf(self.zgen0, self.zgen, self.made_w, self.made_b, n, 100, 128)               # {l_Z_IAF: Z} (:149)
         self.dec_forward(self.DG, self.zgen)                                                   # X_gen
-        self.enc_forward(self.EG, self.DG["xhat"], targets=(0, 2), acc_target=2)               # p_X_gen vs p1 / p3
+        self.enc_forward(self.EG, self.DG["xhat"] if xgen_override is None else xgen_override, targets=(0, 2), acc_target=2)  # p_X_gen
 
     def metrics(self):
         """All scalar losses of train_IAN.py:169-250,279 as a dict (one device->host copy).  Means are over the GLOBAL batch."""

@@ -156,6 +156,27 @@ def test_edit_loop_trajectory(arch):
     assert rel(m.sample_at(z_gpu), tw.np_decode(z_ref)) < TOL
 
 
+def test_decoder_forward_cache_is_transparent():
+    """imgradRGB(z) right after sample_at(z) (NPE.py:205,218) reuses the resident decoder activations: same bits as a
+    cold call, and a different latent / an intervening call invalidates the cache."""
+    m, _, _ = model_for("IAN_simple")
+    z1, z2 = O.make_latents(1, seed=31), O.make_latents(1, seed=32)
+    rgb = red_rgb()
+    os.environ["IAN_NO_DEC_CACHE"] = "1"
+    try:
+        cold1, cold2 = m.imgradRGB(26, 26, 30, 30, rgb, z1), m.imgradRGB(26, 26, 30, 30, rgb, z2)
+    finally:
+        del os.environ["IAN_NO_DEC_CACHE"]
+    m.sample_at(z1)
+    assert np.array_equal(m.imgradRGB(26, 26, 30, 30, rgb, z1), cold1)      # hit
+    assert np.array_equal(m.imgradRGB(26, 26, 30, 30, rgb, z2), cold2)      # miss: other latent
+    m.sample_at(z1)
+    m.reconstruct(O.make_images(1, seed=3))                                  # clobbers the decoder activations
+    assert np.array_equal(m.imgradRGB(26, 26, 30, 30, rgb, z1), cold1)
+    m.sample_at(np.concatenate([z1, z2]))                                    # batch 2: not cacheable
+    assert np.array_equal(m.imgrad(26, 26, 30, 30, z1), m.imgrad(26, 26, 30, 30, z1.copy()))
+
+
 def test_device_pointers_equal_host_pointers():
     import torch
     m, _, _ = model_for("IAN_simple")
