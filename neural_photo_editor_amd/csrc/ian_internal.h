@@ -61,6 +61,7 @@ struct TgParams {
   int OH, OW, Cout, y_stride;
   int CoutPad;
   unsigned x_bytes, w_bytes;  // buffer-descriptor extents (out-of-range offsets read as zero)
+  int variant;                // K-loop schedule (kernels_tapgemm.hip)
 };
 
 struct TgReduceParams {
@@ -125,6 +126,20 @@ hipError_t launch_deconv_out_bwd(const float* g, const float* w, float* dx, cons
 hipError_t launch_dact_nchw(float* g, const float* y, const float* scale, int n, int c, int hw, int act,
                             hipStream_t s);
 
+// few-filter MDCL forward on the VALU (RGB-Beta head): weights read from the forward slab [tap][CoutPad][CinPad]
+struct MdcHeadArgs {
+  const float* x;  // NHWC, pixel stride xs
+  const float* w;  // forward slab; tap t, filter co, channel ci at t*w_tap_stride + co*w_row_stride + ci
+  const float* res;
+  const float* scale;
+  const float* shift;
+  float* y;        // NHWC, pixel stride ys
+  int H, W, xs, ys, ntaps, act;
+  long long w_tap_stride;
+  int w_row_stride;
+  signed char dy[48], dx[48];
+};
+hipError_t launch_mdc_head(const MdcHeadArgs& a, int n, int Cin, int Cout, hipStream_t s);
 // identity-edge gradient hand-over: gd[p,c] (+)= gs[p,coff+c] * act'(y[p,c]) * scale[c]   (NHWC, strides ss / ds)
 hipError_t launch_grad_pass(const float* gs, int ss, int coff, float* gd, const float* y, int ds, const float* scale,
                             long long npix, int C, int act, int accumulate, hipStream_t s);

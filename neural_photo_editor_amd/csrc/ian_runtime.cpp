@@ -38,6 +38,7 @@ static inline int ilog2_exact(int v) {
 }
 
 struct Schedule {
+  int variant = -1;
   int cfg = 0;
   int nitems = 0;
   TgItem* d_items = nullptr;
@@ -51,6 +52,7 @@ struct Schedule {
 struct TgChoice {  // autotuned (or forced) schedule shape for one (layer, batch)
   int cfg = -1;        // enum TgConfig, -1 = heuristic
   int max_steps = -1;  // -1 = heuristic, 0 = never split K, >0 = split so that no item exceeds this many K-steps
+  int variant = -1;    // K-loop schedule of tapgemm_kernel, -1 = the handle's option
 };
 
 // one linear map executed by the tapgemm kernel (forward or backward-data form of an op)
@@ -106,6 +108,8 @@ struct Options {
   int tg_xcd_group = 8;       // supergroup edge (tiles) dealt to one XCD
   int tg_prefer_nosplit = 1;  // try smaller tiles before resorting to split-K
   int tg_nosplit_min_out = 1 << 30;  // outputs (M*Cout) above which 64x64 is forced even if it under-fills
+  int mdc_head = 1;                  // few-filter MDCL layers on the VALU head kernel instead of tapgemm
+  int tg_variant = 2;                // K-loop schedule of tapgemm_kernel (kernels_tapgemm.hip); autotune picks per layer
 };
 
 }  // namespace
@@ -593,6 +597,7 @@ int pick_config(const ian_handle* h, const TgLayer& L, int M) {
 void build_schedule(const ian_handle* h, const TgLayer& L, int nimg, Schedule& S, const TgChoice& ch) {
   const int M = nimg * L.QH * L.QW;
   S.cfg = (ch.cfg >= 0 && ch.cfg < TG_NCONFIG && L.CoutPad % tg_shape(ch.cfg).bn == 0) ? ch.cfg : pick_config(h, L, M);
+  S.variant = ch.variant;
   const TgShape sh = tg_shape(S.cfg);
   const int tiles_m = (M + sh.bm - 1) / sh.bm;
   const int tiles_n = (L.Cout + sh.bn - 1) / sh.bn;
@@ -759,6 +764,7 @@ int run_tapgemm(ian_handle* h, TgLayer& L, int nimg, const float* x, float* y, i
   if (xb > 0xFFFFFFF0ull) return fail(h, -7, "batch %d makes a %zu-byte activation: above the 4 GiB buffer-descriptor range, split the batch", nimg, xb);
   p.x_bytes = (unsigned)xb;
   p.w_bytes = (unsigned)(L.w_floats * sizeof(float));
+  p.variant = S->variant >= 0 ? S->variant : h->opt.tg_variant;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (h->prof) {
     if (h->ev_used == h->ev_pool.size()) {
@@ -784,6 +790,15 @@ int run_tapgemm(ian_handle* h, TgLayer& L, int nimg, const float* x, float* y, i
     h->prof_launches += 1;
   }
   return 0;
+}
+
+bool mdc_head_eligible(const ian_handle* h, const OpPlan& op) {
+  const TgLayer& L = op.fwd;
+  if (!h->opt.mdc_head || L.Cout > 4 || (L.Cin != 128 && L.Cin != 64) || L.cin_real != L.Cin) return false;
+  if ((L.IH % 4) || (L.IW % 16) || L.taps.size() > 48 || L.classes.size() != 1) return false;
+  for (auto& t : L.taps)
+    if (t.dy < -4 || t.dy > 4 || t.dx < -4 || t.dx > 4) return false;
+  return true;
 }
 
 TgEpilogue fwd_epi(const OpPlan& op, const float* res) {
@@ -817,6 +832,16 @@ int run_op_fwd(ian_handle* h, OpPlan& op, int n, hipStream_t st) {
       return run_tapgemm(h, op.fwd, n, src.d, dst.d, dst.cs, fwd_epi(op, nullptr), st);
     case IAN_OP_MDC3:
       if (op.d.src2 >= 0) res = h->slots[op.d.src2].d;
+      if (mdc_head_eligible(h, op)) {  // few output filters: VALU kernel instead of a 16x padded MFMA tile
+        const TgLayer& L = op.fwd;
+        MdcHeadArgs a;
+        a.x = src.d; a.w = L.d_w; a.res = res; a.scale = op.d_scale; a.shift = op.d_shift; a.y = dst.d;
+        a.H = L.IH; a.W = L.IW; a.xs = src.cs; a.ys = dst.cs; a.ntaps = (int)L.taps.size(); a.act = op.d.act;
+        a.w_tap_stride = (long long)L.CoutPad * L.Cin; a.w_row_stride = L.Cin;
+        for (int t = 0; t < a.ntaps; ++t) { a.dy[t] = (signed char)L.taps[t].dy; a.dx[t] = (signed char)L.taps[t].dx; }
+        HIPCHK(h, launch_mdc_head(a, n, L.Cin, L.Cout, st));
+        return 0;
+      }
       return run_tapgemm(h, op.fwd, n, src.d, dst.d, dst.cs, fwd_epi(op, res), st);
     case IAN_OP_DENSE:
       return run_tapgemm(h, op.fwd, n, src.d, dst.d, (int)dst.per_image(), fwd_epi(op, nullptr), st);
@@ -880,10 +905,13 @@ std::vector<TgChoice> tune_candidates(const TgLayer& L, int nimg) {
         if (slabs * sh.bm * sh.bn * 4 > (512ll << 20)) continue;  // slab workspace cap
         if (slabs > 16384) continue;
       }
-      TgChoice c;
-      c.cfg = cfg;
-      c.max_steps = ms;
-      out.push_back(c);
+      for (int var : {1, 2}) {
+        TgChoice c;
+        c.cfg = cfg;
+        c.max_steps = ms;
+        c.variant = var;
+        out.push_back(c);
+      }
     }
   }
   return out;
@@ -941,11 +969,12 @@ void tune_cache_load(TuneCache& c) {
   FILE* f = fopen(path, "r");
   if (!f) return;
   char dir[16], name[256];
-  int n, cfg, ms;
-  while (fscanf(f, "%d %15s %255s %d %d", &n, dir, name, &cfg, &ms) == 5) {
+  int n, cfg, ms, var;
+  while (fscanf(f, "%d %15s %255s %d %d %d", &n, dir, name, &cfg, &ms, &var) == 6) {
     TgChoice ch;
     ch.cfg = cfg;
     ch.max_steps = ms;
+    ch.variant = var;
     c[tune_key(n, dir, name)] = ch;
   }
   fclose(f);
@@ -955,7 +984,7 @@ void tune_cache_store(const TuneCache& c) {
   if (!path) return;
   FILE* f = fopen(path, "w");
   if (!f) return;
-  for (auto& kv : c) fprintf(f, "%s %d %d\n", kv.first.c_str(), kv.second.cfg, kv.second.max_steps);
+  for (auto& kv : c) fprintf(f, "%s %d %d %d\n", kv.first.c_str(), kv.second.cfg, kv.second.max_steps, kv.second.variant);
   fclose(f);
 }
 
@@ -1431,8 +1460,8 @@ int ian_autotune(ian_handle* h, int32_t n, int32_t what, void* stream) {
       if ((rc = tune_layer(h, op.fwd, n, st, [&]() { return run_op_fwd(h, *opp, n, st); }, &best, &ms))) break;
       cache[tune_key(n, "fwd", op.name)] = best;
       if (verbose)
-        fprintf(stderr, "[ian_autotune] n=%d fwd %-14s -> tile %s, max K-steps/item %d : %.1f us (%.1f TF/s)\n", n,
-                op.name.c_str(), cfg_names[best.cfg], best.max_steps, ms * 1e3,
+        fprintf(stderr, "[ian_autotune] n=%d fwd %-14s -> tile %s, max K-steps/item %d, schedule %d : %.1f us (%.1f TF/s)\n", n,
+                op.name.c_str(), cfg_names[best.cfg], best.max_steps, best.variant, ms * 1e3,
                 2.0 * op.fwd.macs_per_image() * n / (ms * 1e-3) / 1e12);
     }
   }
@@ -1564,6 +1593,8 @@ int ian_set_option(ian_handle* h, const char* key, int32_t value) {
   else if (k == "tg_xcd_group") h->opt.tg_xcd_group = std::max(1, value);
   else if (k == "tg_prefer_nosplit") h->opt.tg_prefer_nosplit = value;
   else if (k == "tg_nosplit_min_out") h->opt.tg_nosplit_min_out = value;
+  else if (k == "tg_variant") h->opt.tg_variant = value;
+  else if (k == "mdc_head") h->opt.mdc_head = value;
   else return fail(h, -1, "unknown option '%s'", key);
   for (auto& op : h->ops) {  // schedules depend on the options
     free_schedules(op.fwd);

@@ -446,6 +446,105 @@ hipError_t launch_dact_nchw(float* g, const float* y, const float* scale, int n,
 }
 
 // ------------------------------------------------------------------------------------------------
+// MDCL with a handful of output filters (RGB-Beta head, IAN.py:183-206: 128 -> 2 channels at 64x64, scales [2,3,4]).
+// On the MFMA path these layers pad Cout 2 -> 32 (16x wasted matrix work, 35 % of the full-IAN step); they are
+// really FMA / LDS-bandwidth work, so: block = 4x16 output pixels, input tile with a 4-pixel halo (12x24 pixels x Cin)
+// staged in LDS with a Cin+4 pixel stride, lane = pixel, wave = quarter of the input channels (all taps), filter taps
+// wave-uniform -> scalar loads straight from the forward slab [tap][CoutPad][CinPad]; the four channel-slice partials
+// meet in LDS.  A 16-lane ds_read_b128 service group is one 16-pixel row: 16 distinct bank slots for any tap shift.
+// ------------------------------------------------------------------------------------------------
+constexpr int MH_HALO = 4, MH_TH = 4, MH_TW = 16, MH_PH = MH_TH + 2 * MH_HALO, MH_PW = MH_TW + 2 * MH_HALO;
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void mdc_head_kernel(MdcHeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int PS = CIN + 4, CW = CIN / 4;
+  const int tiles_x = a.W / MH_TW;
+  const int n = blockIdx.y, ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+  const int iy0 = ty * MH_TH - MH_HALO, ix0 = tx * MH_TW - MH_HALO;
+  for (int i = threadIdx.x; i < MH_PH * MH_PW * (CIN / 4); i += 256) {
+    const int pix = i / (CIN / 4), c4 = (i % (CIN / 4)) * 4;
+    const int iy = iy0 + pix / MH_PW, ix = ix0 + pix % MH_PW;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+      v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.xs + c4);
+    *reinterpret_cast<float4*>(sm + pix * PS + c4) = v;
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  // ds_read_b128 service groups: {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32 -> group = tile row, position = column
+  const int l5 = lane & 31;
+  const bool g1 = (l5 >= 4 && l5 < 12) || (l5 >= 16 && l5 < 20) || l5 >= 28;
+  const int qx = g1 ? (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16)) : (l5 < 4 ? l5 : (l5 < 16 ? l5 - 8 : l5 - 12));
+  const int qy = (lane >> 5) * 2 + (g1 ? 1 : 0);
+  const int cbase = wave * CW;
+  float acc[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+  for (int t = 0; t < a.ntaps; ++t) {
+    const int dy = a.dy[t], dx = a.dx[t];  // wave-uniform
+    const float* xs = sm + ((qy + dy + MH_HALO) * MH_PW + (qx + dx + MH_HALO)) * PS + cbase;
+    const float* wt = a.w + (size_t)t * a.w_tap_stride + cbase;
+#pragma unroll
+    for (int c = 0; c < CW; c += 4) {
+      const float4 xv = *reinterpret_cast<const float4*>(xs + c);
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) {
+        const float4 wv = *reinterpret_cast<const float4*>(wt + co * a.w_row_stride + c);
+        float v = acc[co];
+        v = fmaf(xv.x, wv.x, v);
+        v = fmaf(xv.y, wv.y, v);
+        v = fmaf(xv.z, wv.z, v);
+        v = fmaf(xv.w, wv.w, v);
+        acc[co] = v;
+      }
+    }
+  }
+  __syncthreads();  // input tile dead: partials [wave][co][lane]
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) sm[(wave * COUT + co) * 64 + lane] = acc[co];
+  __syncthreads();
+  // thread -> (pixel, co): consecutive threads write consecutive channels of a pixel
+  for (int i = threadIdx.x; i < 64 * COUT; i += 256) {
+    const int co = i % COUT, pl = i / COUT;  // pl: pixel in row-major tile order
+    const int py = pl / MH_TW, px = pl % MH_TW;
+    // inverse of the lane map: row py = group (half = py>>1, g1 = py&1), column px = position
+    const int gl = (py & 1) ? (px < 8 ? px + 4 : (px < 12 ? px + 8 : px + 16)) : (px < 4 ? px : (px < 8 ? px + 8 : px + 12));
+    const int src = (py >> 1) * 32 + gl;
+    float v = sm[(0 * COUT + co) * 64 + src] + sm[(1 * COUT + co) * 64 + src] + sm[(2 * COUT + co) * 64 + src] + sm[(3 * COUT + co) * 64 + src];
+    const size_t off = ((size_t)(n * a.H + ty * MH_TH + py) * a.W + tx * MH_TW + px) * a.ys + co;
+    if (a.res) v += a.res[off];
+    v = v * (a.scale ? a.scale[co] : 1.f) + (a.shift ? a.shift[co] : 0.f);
+    a.y[off] = m_act(v, a.act);
+  }
+}
+
+hipError_t launch_mdc_head(const MdcHeadArgs& a, int n, int Cin, int Cout, hipStream_t s) {
+  if (Cout < 1 || Cout > 4 || (a.H % MH_TH) || (a.W % MH_TW) || a.ntaps > 48) return hipErrorInvalidValue;
+  dim3 grid((a.H / MH_TH) * (a.W / MH_TW), n);
+  const size_t lds = (size_t)MH_PH * MH_PW * (Cin + 4) * sizeof(float);
+#define MH_LAUNCH(CI, CO)                                                                                         \
+  {                                                                                                               \
+    static bool attr = false;                                                                                     \
+    auto k = mdc_head_kernel<CI, CO>;                                                                             \
+    if (!attr) {                                                                                                  \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return e;                                                                              \
+      attr = true;                                                                                                \
+    }                                                                                                             \
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                                            \
+    return hipGetLastError();                                                                                     \
+  }
+  if (Cin == 128 && Cout <= 2) MH_LAUNCH(128, 2)
+  if (Cin == 128) MH_LAUNCH(128, 4)
+  if (Cin == 64 && Cout <= 2) MH_LAUNCH(64, 2)
+  if (Cin == 64) MH_LAUNCH(64, 4)
+#undef MH_LAUNCH
+  return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------------
 // latent-brush backward through the non-GEMM nodes of the full IAN decoder (IAN.py:139-207)
 // ------------------------------------------------------------------------------------------------
 // Gradient hand-over along an identity edge (ElemwiseSum residual layers.py:412-416, stand-alone BatchNorm

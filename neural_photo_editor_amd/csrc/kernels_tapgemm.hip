@@ -49,18 +49,39 @@ __device__ __forceinline__ float act_grad(float y) {
   return 1.f;
 }
 
+__device__ __forceinline__ float act_apply_rt(float v, int act) {
+  switch (act) {
+    case 1: return act_apply<1>(v);
+    case 2: return act_apply<2>(v);
+    case 3: return act_apply<3>(v);
+    case 4: return act_apply<4>(v);
+    case 5: return act_apply<5>(v);
+    default: return v;
+  }
+}
+__device__ __forceinline__ float act_grad_rt(float y, int act) {
+  switch (act) {
+    case 1: return act_grad<1>(y);
+    case 2: return act_grad<2>(y);
+    case 3: return act_grad<3>(y);
+    case 4: return act_grad<4>(y);
+    case 5: return act_grad<5>(y);
+    default: return 1.f;
+  }
+}
 // FWD: y = act((acc + res) * scale + shift)          BWD: y = acc * act'(yfwd) * scale + res
-template <int ACT, int MODE>
+// The activation and the mode are wave-uniform RUNTIME values: the epilogue runs once per tile, so a uniform
+// branch costs nothing next to the K loop, and the kernels are instantiated once instead of 12 times.
 __device__ __forceinline__ float epilogue_value(const TgEpilogue& e, float acc, size_t yoff, int c) {
   const int si = e.scale_period ? (int)(yoff % (size_t)e.scale_period) : c;
   const float sc = e.scale ? e.scale[si] : 1.f;
-  if (MODE == TG_EPI_FWD) {
+  if (e.mode == TG_EPI_FWD) {
     if (e.res) acc += e.res[yoff];
     const float sh = e.shift ? e.shift[si] : 0.f;
-    return act_apply<ACT>(acc * sc + sh);
+    return act_apply_rt(acc * sc + sh, e.act);
   }
   const float yf = e.yfwd ? e.yfwd[yoff] : 0.f;
-  float g = acc * act_grad<ACT>(yf) * sc;
+  float g = acc * act_grad_rt(yf, e.act) * sc;
   if (e.res) g += e.res[yoff];
   return g;
 }
@@ -98,7 +119,28 @@ __device__ __forceinline__ void tg_compute(const float* a_s, const float* b_s, f
   }
 }
 
-template <int BM, int BN, int WM, int WN, int ACT, int MODE>
+// one 8-wide k group (4 MFMA k-steps): fragment loads and MFMAs separately, for software pipelining
+template <int FM, int FN>
+__device__ __forceinline__ void tg_frag_load(const float* a_s, const float* b_s, int kk, float4 (&av)[FM], float4 (&bv)[FN]) {
+#pragma unroll
+  for (int i = 0; i < FM; ++i) av[i] = *reinterpret_cast<const float4*>(a_s + i * 32 * TG_LDS + kk * 8);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) bv[j] = *reinterpret_cast<const float4*>(b_s + j * 32 * TG_LDS + kk * 8);
+}
+template <int FM, int FN>
+__device__ __forceinline__ void tg_frag_mfma(const float4 (&av)[FM], const float4 (&bv)[FN], f32x16 (&acc)[FM][FN]) {
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void tg_store(const TgParams& p, const TgItem& it, const TgClass& cl,
                                          f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wm, int wn, int lane) {
   constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
@@ -121,13 +163,18 @@ __device__ __forceinline__ void tg_store(const TgParams& p, const TgItem& it, co
         const int c = it.n0 + wn * (BN / WN) + j * 32 + col_l;
         if (c < p.Cout) {
           const size_t yoff = pix * p.y_stride + c;
-          p.y[yoff] = epilogue_value<ACT, MODE>(p.epi, acc[i][j][r], yoff, c);
+          p.y[yoff] = epilogue_value(p.epi, acc[i][j][r], yoff, c);
         }
       }
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+// VAR selects the K-loop schedule (same arithmetic, same summation order -> bitwise identical results):
+//   0: loads -> 64 MFMAs -> LDS stores -> barrier                (compiler-scheduled)
+//   1: loads -> kk 0,1 -> LDS stores -> kk 2,3 -> barrier         (stores hidden under the second half's MFMAs)
+//   2: rotated: the fragments of the last k group are read before the barrier and their MFMAs issued after it,
+//      covering the barrier, the next tile's global-load issue and the first fragment reads of the new buffer
+template <int BM, int BN, int WM, int WN, int VAR>
 __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
   constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
   constexpr int A_CH = BM / 32, B_CH = BN / 32;
@@ -219,17 +266,75 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
 
   const int nks = it.ks1 - it.ks0;
   int cur = 0;
-  for (int s = 0; s < nks - 1; ++s) {
-    TG_LOAD_TILE();  // K-step s+1: in flight during the MFMAs below
-    // hipcc otherwise sinks the loads next to their ds_write (to recycle fragment registers), exposing the
-    // whole global-load latency every K-step: pin the issue point.
-    __builtin_amdgcn_sched_barrier(0);
+  if (VAR == 0) {
+    for (int s = 0; s < nks - 1; ++s) {
+      TG_LOAD_TILE();  // K-step s+1: in flight during the MFMAs below
+      // hipcc otherwise sinks the loads next to their ds_write (to recycle fragment registers), exposing the
+      // whole global-load latency every K-step: pin the issue point.
+      __builtin_amdgcn_sched_barrier(0);
+      tg_compute<FM, FN>(a_base + cur * BM * TG_LDS, b_base + cur * BN * TG_LDS, acc);
+      TG_STORE_TILE(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
     tg_compute<FM, FN>(a_base + cur * BM * TG_LDS, b_base + cur * BN * TG_LDS, acc);
-    TG_STORE_TILE(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+  } else if (VAR == 1) {
+    float4 av[FM], bv[FN];
+    for (int s = 0; s < nks - 1; ++s) {
+      const float* a_s = a_base + cur * BM * TG_LDS;
+      const float* b_s = b_base + cur * BN * TG_LDS;
+      TG_LOAD_TILE();
+      __builtin_amdgcn_sched_barrier(0);
+      tg_frag_load<FM, FN>(a_s, b_s, 0, av, bv);
+      tg_frag_mfma<FM, FN>(av, bv, acc);
+      tg_frag_load<FM, FN>(a_s, b_s, 1, av, bv);
+      tg_frag_mfma<FM, FN>(av, bv, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      TG_STORE_TILE(cur ^ 1);  // the other buffer: nobody reads it during this step
+      __builtin_amdgcn_sched_barrier(0);
+      tg_frag_load<FM, FN>(a_s, b_s, 2, av, bv);
+      tg_frag_mfma<FM, FN>(av, bv, acc);
+      tg_frag_load<FM, FN>(a_s, b_s, 3, av, bv);
+      tg_frag_mfma<FM, FN>(av, bv, acc);
+      __syncthreads();
+      cur ^= 1;
+    }
+    tg_compute<FM, FN>(a_base + cur * BM * TG_LDS, b_base + cur * BN * TG_LDS, acc);
+  } else {
+    float4 av[FM], bv[FN], aw[FM], bw[FN];
+    tg_frag_load<FM, FN>(a_base, b_base, 0, av, bv);
+    for (int s = 0; s < nks - 1; ++s) {
+      const float* a_s = a_base + cur * BM * TG_LDS;
+      const float* b_s = b_base + cur * BN * TG_LDS;
+      TG_LOAD_TILE();
+      __builtin_amdgcn_sched_barrier(0);
+      tg_frag_load<FM, FN>(a_s, b_s, 1, aw, bw);
+      tg_frag_mfma<FM, FN>(av, bv, acc);   // kk 0 (fragments read before the previous barrier / in the prologue)
+      tg_frag_load<FM, FN>(a_s, b_s, 2, av, bv);
+      tg_frag_mfma<FM, FN>(aw, bw, acc);   // kk 1
+      __builtin_amdgcn_sched_barrier(0);
+      TG_STORE_TILE(cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      tg_frag_load<FM, FN>(a_s, b_s, 3, aw, bw);
+      tg_frag_mfma<FM, FN>(av, bv, acc);   // kk 2
+      __syncthreads();                     // all reads of `cur` (incl. kk 3 into aw/bw) and all writes of cur^1 done
+      cur ^= 1;
+      tg_frag_load<FM, FN>(a_base + cur * BM * TG_LDS, b_base + cur * BN * TG_LDS, 0, av, bv);
+      __builtin_amdgcn_sched_barrier(0);
+      tg_frag_mfma<FM, FN>(aw, bw, acc);   // kk 3 of the previous buffer: covers the new buffer's first reads
+    }
+    {
+      const float* a_s = a_base + cur * BM * TG_LDS;
+      const float* b_s = b_base + cur * BN * TG_LDS;
+      tg_frag_load<FM, FN>(a_s, b_s, 1, aw, bw);
+      tg_frag_mfma<FM, FN>(av, bv, acc);
+      tg_frag_load<FM, FN>(a_s, b_s, 2, av, bv);
+      tg_frag_mfma<FM, FN>(aw, bw, acc);
+      tg_frag_load<FM, FN>(a_s, b_s, 3, aw, bw);
+      tg_frag_mfma<FM, FN>(av, bv, acc);
+      tg_frag_mfma<FM, FN>(aw, bw, acc);
+    }
   }
-  tg_compute<FM, FN>(a_base + cur * BM * TG_LDS, b_base + cur * BN * TG_LDS, acc);
 #undef TG_LOAD_TILE
 #undef TG_STORE_TILE
 
@@ -250,29 +355,11 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
         }
     return;
   }
-  if (p.epi.mode == TG_EPI_FWD) {
-    switch (p.epi.act) {
-      case 1: tg_store<BM, BN, WM, WN, 1, TG_EPI_FWD>(p, it, cl, acc, wm, wn, lane); break;
-      case 2: tg_store<BM, BN, WM, WN, 2, TG_EPI_FWD>(p, it, cl, acc, wm, wn, lane); break;
-      case 3: tg_store<BM, BN, WM, WN, 3, TG_EPI_FWD>(p, it, cl, acc, wm, wn, lane); break;
-      case 4: tg_store<BM, BN, WM, WN, 4, TG_EPI_FWD>(p, it, cl, acc, wm, wn, lane); break;
-      case 5: tg_store<BM, BN, WM, WN, 5, TG_EPI_FWD>(p, it, cl, acc, wm, wn, lane); break;
-      default: tg_store<BM, BN, WM, WN, 0, TG_EPI_FWD>(p, it, cl, acc, wm, wn, lane); break;
-    }
-  } else {
-    switch (p.epi.act) {
-      case 1: tg_store<BM, BN, WM, WN, 1, TG_EPI_BWD>(p, it, cl, acc, wm, wn, lane); break;
-      case 2: tg_store<BM, BN, WM, WN, 2, TG_EPI_BWD>(p, it, cl, acc, wm, wn, lane); break;
-      case 3: tg_store<BM, BN, WM, WN, 3, TG_EPI_BWD>(p, it, cl, acc, wm, wn, lane); break;
-      case 4: tg_store<BM, BN, WM, WN, 4, TG_EPI_BWD>(p, it, cl, acc, wm, wn, lane); break;
-      case 5: tg_store<BM, BN, WM, WN, 5, TG_EPI_BWD>(p, it, cl, acc, wm, wn, lane); break;
-      default: tg_store<BM, BN, WM, WN, 0, TG_EPI_BWD>(p, it, cl, acc, wm, wn, lane); break;
-    }
-  }
+  tg_store<BM, BN, WM, WN>(p, it, cl, acc, wm, wn, lane);
 }
 
 // split-K second pass: y = epilogue(sum of slabs).  Block = (tile, group of RPI rows); float4 along channels.
-template <int BM, int BN, int ACT, int MODE>
+template <int BM, int BN>
 __device__ __forceinline__ void tg_reduce_body(const TgReduceParams& p) {
   constexpr int CG = BN / 4;     // float4 groups per row
   constexpr int RPI = 256 / CG;  // rows per block
@@ -310,45 +397,27 @@ __device__ __forceinline__ void tg_reduce_body(const TgReduceParams& p) {
   const float v[4] = {s.x, s.y, s.z, s.w};
   if (c + 3 < p.Cout) {
     float4 o;
-    o.x = epilogue_value<ACT, MODE>(p.epi, v[0], yoff + 0, c + 0);
-    o.y = epilogue_value<ACT, MODE>(p.epi, v[1], yoff + 1, c + 1);
-    o.z = epilogue_value<ACT, MODE>(p.epi, v[2], yoff + 2, c + 2);
-    o.w = epilogue_value<ACT, MODE>(p.epi, v[3], yoff + 3, c + 3);
+    o.x = epilogue_value(p.epi, v[0], yoff + 0, c + 0);
+    o.y = epilogue_value(p.epi, v[1], yoff + 1, c + 1);
+    o.z = epilogue_value(p.epi, v[2], yoff + 2, c + 2);
+    o.w = epilogue_value(p.epi, v[3], yoff + 3, c + 3);
     *reinterpret_cast<float4*>(p.y + yoff) = o;
   } else {
     for (int e = 0; e < 4; ++e)
-      if (c + e < p.Cout) p.y[yoff + e] = epilogue_value<ACT, MODE>(p.epi, v[e], yoff + e, c + e);
+      if (c + e < p.Cout) p.y[yoff + e] = epilogue_value(p.epi, v[e], yoff + e, c + e);
   }
 }
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void tapgemm_reduce_kernel(const TgReduceParams p) {
-  if (p.epi.mode == TG_EPI_FWD) {
-    switch (p.epi.act) {
-      case 1: tg_reduce_body<BM, BN, 1, TG_EPI_FWD>(p); break;
-      case 2: tg_reduce_body<BM, BN, 2, TG_EPI_FWD>(p); break;
-      case 3: tg_reduce_body<BM, BN, 3, TG_EPI_FWD>(p); break;
-      case 4: tg_reduce_body<BM, BN, 4, TG_EPI_FWD>(p); break;
-      case 5: tg_reduce_body<BM, BN, 5, TG_EPI_FWD>(p); break;
-      default: tg_reduce_body<BM, BN, 0, TG_EPI_FWD>(p); break;
-    }
-  } else {
-    switch (p.epi.act) {
-      case 1: tg_reduce_body<BM, BN, 1, TG_EPI_BWD>(p); break;
-      case 2: tg_reduce_body<BM, BN, 2, TG_EPI_BWD>(p); break;
-      case 3: tg_reduce_body<BM, BN, 3, TG_EPI_BWD>(p); break;
-      case 4: tg_reduce_body<BM, BN, 4, TG_EPI_BWD>(p); break;
-      case 5: tg_reduce_body<BM, BN, 5, TG_EPI_BWD>(p); break;
-      default: tg_reduce_body<BM, BN, 0, TG_EPI_BWD>(p); break;
-    }
-  }
+  tg_reduce_body<BM, BN>(p);
 }
 
-template <int BM, int BN, int WM, int WN>
-static hipError_t launch_cfg(const TgParams& p, int nitems, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int VAR>
+static hipError_t launch_var(const TgParams& p, int nitems, hipStream_t s) {
   static bool attr_set = false;
   const size_t lds = (size_t)2 * (BM + BN) * TG_LDS * sizeof(float);
-  auto k = tapgemm_kernel<BM, BN, WM, WN>;
+  auto k = tapgemm_kernel<BM, BN, WM, WN, VAR>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -357,6 +426,15 @@ static hipError_t launch_cfg(const TgParams& p, int nitems, hipStream_t s) {
   }
   hipLaunchKernelGGL(k, dim3(nitems), dim3(256), lds, s, p);
   return hipGetLastError();
+}
+
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_cfg(const TgParams& p, int nitems, hipStream_t s) {
+  switch (p.variant) {
+    case 1: return launch_var<BM, BN, WM, WN, 1>(p, nitems, s);
+    case 2: return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);
+    default: return launch_var<BM, BN, WM, WN, 0>(p, nitems, s);
+  }
 }
 
 hipError_t launch_tapgemm(int cfg, const TgParams& p, int nitems, hipStream_t s) {

@@ -102,6 +102,15 @@ def test_every_tile_config_and_split_policy(cfg):
     x = O.make_images(3, seed=7)
     ref = orc.reconstruct(x)
     try:
+        outs = []
+        for var in (0, 1, 2):          # K-loop schedules: same arithmetic in the same order -> identical bits
+            m.handle.set_option("tg_variant", var)
+            m.handle.set_option("tg_cfg", cfg)
+            m.handle.set_option("tg_split", 1)
+            outs.append(m.reconstruct(x))
+            assert rel(outs[-1], ref) < TOL
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+        m.handle.set_option("tg_variant", 0)
         for split in (1, 0):
             m.handle.set_option("tg_cfg", cfg)
             m.handle.set_option("tg_split", split)
@@ -111,7 +120,7 @@ def test_every_tile_config_and_split_policy(cfg):
         m.handle.set_option("tg_split", 1)
         assert rel(m.reconstruct(x), ref) < TOL
     finally:
-        for k, v in (("tg_cfg", -1), ("tg_split", 1), ("tg_target_items", 768), ("tg_min_steps", 16)):
+        for k, v in (("tg_cfg", -1), ("tg_split", 1), ("tg_target_items", 768), ("tg_min_steps", 16), ("tg_variant", 0)):
             m.handle.set_option(k, v)
 
 
