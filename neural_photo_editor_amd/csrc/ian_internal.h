@@ -126,17 +126,19 @@ hipError_t launch_deconv_out_bwd(const float* g, const float* w, float* dx, cons
 hipError_t launch_dact_nchw(float* g, const float* y, const float* scale, int n, int c, int hw, int act,
                             hipStream_t s);
 
-// few-filter MDCL forward on the VALU (RGB-Beta head): weights read from the forward slab [tap][CoutPad][CinPad]
+// few-filter MDCL forward on the VALU (RGB-Beta head).  One launch computes up to MH_MAXCO output filters that read
+// the SAME input map with the SAME tap list -- the filters may belong to different layers (IAN.py:183-199: R, G_a
+// and B_a all read the 128-channel feature map), each with its own weights, destination, residual and activation.
+constexpr int MH_MAXCO = 8;
 struct MdcHeadArgs {
-  const float* x;  // NHWC, pixel stride xs
-  const float* w;  // forward slab; tap t, filter co, channel ci at t*w_tap_stride + co*w_row_stride + ci
-  const float* res;
-  const float* scale;
-  const float* shift;
-  float* y;        // NHWC, pixel stride ys
-  int H, W, xs, ys, ntaps, act;
+  const float* x;              // NHWC, pixel stride xs
+  const float* w[MH_MAXCO];    // per output filter: its row in a forward slab; tap t at + t*w_tap_stride
+  const float* res[MH_MAXCO];  // per output filter: residual tensor (same addressing as y) or nullptr
+  float* y[MH_MAXCO];          // per output filter: destination tensor base
+  float scale[MH_MAXCO], shift[MH_MAXCO];
+  int ys[MH_MAXCO], yc[MH_MAXCO], act[MH_MAXCO];  // pixel stride, channel index, activation
+  int H, W, xs, ntaps;
   long long w_tap_stride;
-  int w_row_stride;
   signed char dy[48], dx[48];
 };
 hipError_t launch_mdc_head(const MdcHeadArgs& a, int n, int Cin, int Cout, hipStream_t s);

@@ -97,6 +97,7 @@ struct OpPlan {
   std::vector<float> h_scale, h_shift;
   float* d_made_w = nullptr;
   float* d_made_b = nullptr;
+  long long head_done_serial = -1;  // run_serial of the call in which a sibling's fused head launch produced this op
 };
 
 struct Options {
@@ -108,7 +109,7 @@ struct Options {
   int tg_xcd_group = 8;       // supergroup edge (tiles) dealt to one XCD
   int tg_prefer_nosplit = 1;  // try smaller tiles before resorting to split-K
   int tg_nosplit_min_out = 1 << 30;  // outputs (M*Cout) above which 64x64 is forced even if it under-fills
-  int mdc_head = 1;                  // few-filter MDCL layers on the VALU head kernel instead of tapgemm
+  int mdc_head = 2;                  // few-filter MDCL layers: 0 = tapgemm, 1 = VALU head kernel, 2 = + sibling layers fused
   int tg_variant = 2;                // K-loop schedule of tapgemm_kernel (kernels_tapgemm.hip); autotune picks per layer
 };
 
@@ -137,6 +138,7 @@ struct ian_handle {
   // decoder-forward cache for the interactive loop (NPE.py:205,218: imgradRGB(z) right after sample_at(z)):
   // the batch-1 decoder activations of the last HOST latent are kept; a gradient call on the same latent skips
   // its forward pass.  Any other use of the decoder slots invalidates it.
+  long long run_serial = 0;  // incremented per executed segment (fused head bookkeeping)
   std::vector<float> dec_cache_z;
   bool dec_cache_valid = false;
   // profiling
@@ -801,6 +803,59 @@ bool mdc_head_eligible(const ian_handle* h, const OpPlan& op) {
   return true;
 }
 
+// Fill the per-filter slots of MdcHeadArgs for one layer; weights/scale/shift are read back from the host copies.
+int mdc_head_add(ian_handle* h, MdcHeadArgs& a, int& nco, const OpPlan& op, float* y, int ys, const float* res) {
+  const TgLayer& L = op.fwd;
+  for (int co = 0; co < L.Cout; ++co) {
+    if (nco >= MH_MAXCO) return fail(h, -4, "mdc head: too many filters");
+    a.w[nco] = L.d_w + (size_t)co * L.Cin;
+    a.res[nco] = res;
+    a.y[nco] = y;
+    a.ys[nco] = ys;
+    a.yc[nco] = co;
+    a.act[nco] = op.d.act;
+    a.scale[nco] = op.h_scale.empty() ? 1.f : op.h_scale[co];
+    a.shift[nco] = op.h_shift.empty() ? 0.f : op.h_shift[co];
+    ++nco;
+  }
+  return 0;
+}
+
+// Inference: few-filter MDCL layers on the VALU kernel.  Sibling layers that read the same map with the same taps and
+// have no residual input are computed by ONE launch when the first of them is reached (their inputs are ready: same
+// source); the others are skipped when their turn comes (OpPlan::head_done_for marks the batch they were computed for).
+int run_mdc_head_group(ian_handle* h, OpPlan& op, int n, hipStream_t st) {
+  if (op.head_done_serial == h->run_serial) return 0;  // already produced by its group leader in this call
+  const TgLayer& L = op.fwd;
+  MdcHeadArgs a;
+  memset(&a, 0, sizeof a);
+  Slot& src = h->slots[op.d.src];
+  a.x = src.d; a.H = L.IH; a.W = L.IW; a.xs = src.cs; a.ntaps = (int)L.taps.size();
+  a.w_tap_stride = (long long)L.CoutPad * L.Cin;
+  for (int t = 0; t < a.ntaps; ++t) { a.dy[t] = (signed char)L.taps[t].dy; a.dx[t] = (signed char)L.taps[t].dx; }
+  int nco = 0, rc;
+  Slot& dst = h->slots[op.d.dst];
+  const float* res = op.d.src2 >= 0 ? h->slots[op.d.src2].d : nullptr;
+  if ((rc = mdc_head_add(h, a, nco, op, dst.d, dst.cs, res))) return rc;
+  if (h->opt.mdc_head >= 2 && op.d.src2 < 0) {
+    for (auto& o : h->ops) {
+      if (&o == &op || o.d.kind != IAN_OP_MDC3 || o.d.segment != op.d.segment || o.d.src != op.d.src || o.d.src2 >= 0) continue;
+      if (o.head_done_serial == h->run_serial || !mdc_head_eligible(h, o)) continue;
+      const TgLayer& M = o.fwd;
+      if (M.taps.size() != L.taps.size() || M.Cin != L.Cin || M.CoutPad != L.CoutPad || nco + M.Cout > MH_MAXCO) continue;
+      bool same = true;
+      for (size_t t = 0; t < L.taps.size(); ++t) same = same && M.taps[t].dy == L.taps[t].dy && M.taps[t].dx == L.taps[t].dx;
+      if (!same) continue;
+      if ((rc = ensure_slot(h, o.d.dst, n))) return rc;
+      Slot& od = h->slots[o.d.dst];
+      if ((rc = mdc_head_add(h, a, nco, o, od.d, od.cs, nullptr))) return rc;
+      o.head_done_serial = h->run_serial;
+    }
+  }
+  HIPCHK(h, launch_mdc_head(a, n, L.Cin, nco, st));
+  return 0;
+}
+
 TgEpilogue fwd_epi(const OpPlan& op, const float* res) {
   TgEpilogue e;
   e.scale = op.d_scale; e.shift = op.d_shift; e.res = res; e.yfwd = nullptr; e.act = op.d.act; e.mode = TG_EPI_FWD;
@@ -832,16 +887,7 @@ int run_op_fwd(ian_handle* h, OpPlan& op, int n, hipStream_t st) {
       return run_tapgemm(h, op.fwd, n, src.d, dst.d, dst.cs, fwd_epi(op, nullptr), st);
     case IAN_OP_MDC3:
       if (op.d.src2 >= 0) res = h->slots[op.d.src2].d;
-      if (mdc_head_eligible(h, op)) {  // few output filters: VALU kernel instead of a 16x padded MFMA tile
-        const TgLayer& L = op.fwd;
-        MdcHeadArgs a;
-        a.x = src.d; a.w = L.d_w; a.res = res; a.scale = op.d_scale; a.shift = op.d_shift; a.y = dst.d;
-        a.H = L.IH; a.W = L.IW; a.xs = src.cs; a.ys = dst.cs; a.ntaps = (int)L.taps.size(); a.act = op.d.act;
-        a.w_tap_stride = (long long)L.CoutPad * L.Cin; a.w_row_stride = L.Cin;
-        for (int t = 0; t < a.ntaps; ++t) { a.dy[t] = (signed char)L.taps[t].dy; a.dx[t] = (signed char)L.taps[t].dx; }
-        HIPCHK(h, launch_mdc_head(a, n, L.Cin, L.Cout, st));
-        return 0;
-      }
+      if (mdc_head_eligible(h, op)) return run_mdc_head_group(h, op, n, st);
       return run_tapgemm(h, op.fwd, n, src.d, dst.d, dst.cs, fwd_epi(op, res), st);
     case IAN_OP_DENSE:
       return run_tapgemm(h, op.fwd, n, src.d, dst.d, (int)dst.per_image(), fwd_epi(op, nullptr), st);
@@ -865,6 +911,7 @@ int run_op_fwd(ian_handle* h, OpPlan& op, int n, hipStream_t st) {
 }
 
 int run_segment(ian_handle* h, int seg, int n, hipStream_t st) {
+  ++h->run_serial;
   for (auto& op : h->ops)
     if (op.d.segment == seg) {
       int rc = run_op_fwd(h, op, n, st);
@@ -1443,6 +1490,7 @@ int ian_autotune(ian_handle* h, int32_t n, int32_t what, void* stream) {
   if (what & 1) {
     for (auto& op : h->ops) {
       if (!op.fwd.valid) continue;
+      if (op.d.kind == IAN_OP_MDC3 && mdc_head_eligible(h, op)) continue;  // runs on the VALU head kernel, nothing to tune
       if (!have(op.d.src, false) || !have(op.d.src2, false) || !have(op.d.dst, false)) {
         h->prof = prof;
         return fail(h, -6, "ian_autotune: run a forward call with batch >= %d first (op '%s' has no activations)", n, op.name.c_str());
@@ -1883,6 +1931,21 @@ int ian_layer_forward(ian_layer* l, const float* x, int32_t n, float* y, int32_t
   TgEpilogue e;
   e.scale = nullptr; e.shift = bias; e.res = res; e.yfwd = nullptr; e.act = act; e.scale_period = 0; e.mode = TG_EPI_FWD;
   if (y_stride <= 0) y_stride = round_up(l->op.fwd.Cout, 32);
+  if (l->op.d.kind == IAN_OP_MDC3 && mdc_head_eligible(&l->ctx, l->op)) {  // RGB-Beta head: VALU kernel
+    const TgLayer& L = l->op.fwd;
+    MdcHeadArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = x; a.H = L.IH; a.W = L.IW; a.xs = L.Cin; a.ntaps = (int)L.taps.size();
+    a.w_tap_stride = (long long)L.CoutPad * L.Cin;
+    for (int t = 0; t < a.ntaps; ++t) { a.dy[t] = (signed char)L.taps[t].dy; a.dx[t] = (signed char)L.taps[t].dx; }
+    if (bias) return lfail(l, -1, "head layers take no bias");
+    for (int co = 0; co < L.Cout; ++co) {
+      a.w[co] = L.d_w + (size_t)co * L.Cin; a.res[co] = res; a.y[co] = y; a.ys[co] = y_stride; a.yc[co] = co; a.act[co] = act;
+      a.scale[co] = 1.f; a.shift[co] = 0.f;
+    }
+    LHIP(l, launch_mdc_head(a, n, L.Cin, L.Cout, (hipStream_t)stream));
+    return 0;
+  }
   return run_tapgemm(&l->ctx, l->op.fwd, n, x, y, y_stride, e, (hipStream_t)stream);
 }
 

@@ -485,13 +485,13 @@ __global__ __launch_bounds__(256) void mdc_head_kernel(MdcHeadArgs a) {
   for (int t = 0; t < a.ntaps; ++t) {
     const int dy = a.dy[t], dx = a.dx[t];  // wave-uniform
     const float* xs = sm + ((qy + dy + MH_HALO) * MH_PW + (qx + dx + MH_HALO)) * PS + cbase;
-    const float* wt = a.w + (size_t)t * a.w_tap_stride + cbase;
+    const long long woff = (long long)t * a.w_tap_stride + cbase;
 #pragma unroll
     for (int c = 0; c < CW; c += 4) {
       const float4 xv = *reinterpret_cast<const float4*>(xs + c);
 #pragma unroll
       for (int co = 0; co < COUT; ++co) {
-        const float4 wv = *reinterpret_cast<const float4*>(wt + co * a.w_row_stride + c);
+        const float4 wv = *reinterpret_cast<const float4*>(a.w[co] + woff + c);  // scalar loads
         float v = acc[co];
         v = fmaf(xv.x, wv.x, v);
         v = fmaf(xv.y, wv.y, v);
@@ -513,15 +513,16 @@ __global__ __launch_bounds__(256) void mdc_head_kernel(MdcHeadArgs a) {
     const int gl = (py & 1) ? (px < 8 ? px + 4 : (px < 12 ? px + 8 : px + 16)) : (px < 4 ? px : (px < 8 ? px + 8 : px + 12));
     const int src = (py >> 1) * 32 + gl;
     float v = sm[(0 * COUT + co) * 64 + src] + sm[(1 * COUT + co) * 64 + src] + sm[(2 * COUT + co) * 64 + src] + sm[(3 * COUT + co) * 64 + src];
-    const size_t off = ((size_t)(n * a.H + ty * MH_TH + py) * a.W + tx * MH_TW + px) * a.ys + co;
-    if (a.res) v += a.res[off];
-    v = v * (a.scale ? a.scale[co] : 1.f) + (a.shift ? a.shift[co] : 0.f);
-    a.y[off] = m_act(v, a.act);
+    const size_t pix = (size_t)(n * a.H + ty * MH_TH + py) * a.W + tx * MH_TW + px;
+    const size_t off = pix * a.ys[co] + a.yc[co];
+    if (a.res[co]) v += a.res[co][off];
+    v = v * a.scale[co] + a.shift[co];
+    a.y[co][off] = m_act(v, a.act[co]);
   }
 }
 
 hipError_t launch_mdc_head(const MdcHeadArgs& a, int n, int Cin, int Cout, hipStream_t s) {
-  if (Cout < 1 || Cout > 4 || (a.H % MH_TH) || (a.W % MH_TW) || a.ntaps > 48) return hipErrorInvalidValue;
+  if (Cout < 1 || Cout > MH_MAXCO || (a.H % MH_TH) || (a.W % MH_TW) || a.ntaps > 48) return hipErrorInvalidValue;
   dim3 grid((a.H / MH_TH) * (a.W / MH_TW), n);
   const size_t lds = (size_t)MH_PH * MH_PW * (Cin + 4) * sizeof(float);
 #define MH_LAUNCH(CI, CO)                                                                                         \
@@ -536,10 +537,18 @@ hipError_t launch_mdc_head(const MdcHeadArgs& a, int n, int Cin, int Cout, hipSt
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                                            \
     return hipGetLastError();                                                                                     \
   }
-  if (Cin == 128 && Cout <= 2) MH_LAUNCH(128, 2)
-  if (Cin == 128) MH_LAUNCH(128, 4)
-  if (Cin == 64 && Cout <= 2) MH_LAUNCH(64, 2)
-  if (Cin == 64) MH_LAUNCH(64, 4)
+  if (Cin == 128) {
+    if (Cout <= 2) MH_LAUNCH(128, 2)
+    if (Cout <= 4) MH_LAUNCH(128, 4)
+    if (Cout <= 6) MH_LAUNCH(128, 6)
+    MH_LAUNCH(128, 8)
+  }
+  if (Cin == 64) {
+    if (Cout <= 2) MH_LAUNCH(64, 2)
+    if (Cout <= 4) MH_LAUNCH(64, 4)
+    if (Cout <= 6) MH_LAUNCH(64, 6)
+    MH_LAUNCH(64, 8)
+  }
 #undef MH_LAUNCH
   return hipErrorInvalidValue;
 }

@@ -95,16 +95,20 @@ __global__ __launch_bounds__(256) void colstats_kernel(ColStatsArgs a) {
 }
 __global__ __launch_bounds__(256) void colstats_finalize_kernel(const float* __restrict__ partial, int nchunks, int C,
                                                                 float* __restrict__ sums) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 2 * C) return;
+  __shared__ float red[256];
+  const int col = threadIdx.x & 63, lane = threadIdx.x >> 6;  // 64 columns x 4 chunk lanes (fixed summation order)
+  const int i = blockIdx.x * 64 + col;
   float s = 0.f;
-  for (int k = 0; k < nchunks; ++k) s += partial[(size_t)k * 2 * C + i];
-  sums[i] = s;
+  if (i < 2 * C)
+    for (int k = lane; k < nchunks; k += 4) s += partial[(size_t)k * 2 * C + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (lane == 0 && i < 2 * C) sums[i] = (red[col] + red[col + 64]) + (red[col + 128] + red[col + 192]);
 }
 hipError_t launch_colstats(const ColStatsArgs& a, int nchunks, float* sums, hipStream_t s) {
   if (a.C & 3) return hipErrorInvalidValue;
   hipLaunchKernelGGL(colstats_kernel, dim3(nchunks, (a.C + 255) / 256), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(colstats_finalize_kernel, dim3((2 * a.C + 255) / 256), dim3(256), 0, s, a.partial, nchunks, a.C, sums);
+  hipLaunchKernelGGL(colstats_finalize_kernel, dim3((2 * a.C + 63) / 64), dim3(256), 0, s, a.partial, nchunks, a.C, sums);
   return hipGetLastError();
 }
 
@@ -233,50 +237,73 @@ hipError_t launch_globalpool_bwd(const float* dy, float* dx, int n, int hw, int 
 // ------------------------------------------------------------------------------------------------
 // MinibatchLayer (layers.py:486-524)
 // ------------------------------------------------------------------------------------------------
-// W = theta * (exp(log_weight_scale) / sqrt(sum_i theta^2))  (layers.py:494): one thread per column (k,d)
+// W = theta * (exp(log_weight_scale) / sqrt(sum_i theta^2))  (layers.py:494).  Block = 32 columns (k,d) x 8 row lanes.
 __global__ __launch_bounds__(256) void mb_weight_kernel(const float* __restrict__ theta, const float* __restrict__ lws,
                                                         float* __restrict__ W, float* __restrict__ colscale, int nin,
                                                         int ncol) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= ncol) return;
+  __shared__ float red[256];
+  const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
   float ss = 0.f;
-  for (int i = 0; i < nin; ++i) {
-    const float t = theta[(size_t)i * ncol + j];
-    ss += t * t;
-  }
-  const float sc = expf(lws[j]) / sqrtf(ss);
-  colscale[j] = sc;
-  for (int i = 0; i < nin; ++i) W[(size_t)i * ncol + j] = theta[(size_t)i * ncol + j] * sc;
+  if (j < ncol)
+    for (int i = rl; i < nin; i += 8) {
+      const float t = theta[(size_t)i * ncol + j];
+      ss += t * t;
+    }
+  red[threadIdx.x] = ss;
+  __syncthreads();
+  if (j >= ncol) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) tot += red[c + 32 * k];
+  const float sc = expf(lws[j]) / sqrtf(tot);
+  if (rl == 0) colscale[j] = sc;
+  for (int i = rl; i < nin; i += 8) W[(size_t)i * ncol + j] = theta[(size_t)i * ncol + j] * sc;
 }
 // dtheta[i,j] = dW[i,j]*s_j - theta[i,j]*s_j*(sum_i' dW[i',j]*theta[i',j]) / sum_i' theta[i',j]^2 ; dlws[j] = sum_i dW[i,j]*W[i,j]
 __global__ __launch_bounds__(256) void mb_weight_bwd_kernel(const float* __restrict__ theta,
                                                             const float* __restrict__ colscale,
                                                             const float* __restrict__ dW, float* __restrict__ dtheta,
                                                             float* __restrict__ dlws, int nin, int ncol, int accumulate) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= ncol) return;
+  __shared__ float red[2][256];
+  const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
   float ss = 0.f, dot = 0.f;
-  for (int i = 0; i < nin; ++i) {
-    const float t = theta[(size_t)i * ncol + j];
-    ss += t * t;
-    dot += dW[(size_t)i * ncol + j] * t;
+  if (j < ncol)
+    for (int i = rl; i < nin; i += 8) {
+      const float t = theta[(size_t)i * ncol + j];
+      ss += t * t;
+      dot += dW[(size_t)i * ncol + j] * t;
+    }
+  red[0][threadIdx.x] = ss;
+  red[1][threadIdx.x] = dot;
+  __syncthreads();
+  if (j >= ncol) return;
+  ss = 0.f;
+  dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    ss += red[0][c + 32 * k];
+    dot += red[1][c + 32 * k];
   }
   const float sc = colscale[j];
-  for (int i = 0; i < nin; ++i) {
+  for (int i = rl; i < nin; i += 8) {
     const size_t o = (size_t)i * ncol + j;
     const float g = dW[o] * sc - theta[o] * sc * dot / ss;
     dtheta[o] = accumulate ? dtheta[o] + g : g;
   }
-  const float gl = dot * sc;
-  dlws[j] = accumulate ? dlws[j] + gl : gl;
+  if (rl == 0) {
+    const float gl = dot * sc;
+    dlws[j] = accumulate ? dlws[j] + gl : gl;
+  }
 }
 hipError_t launch_mb_weight(const float* theta, const float* lws, float* W, float* colscale, int nin, int ncol, hipStream_t s) {
-  hipLaunchKernelGGL(mb_weight_kernel, dim3((ncol + 255) / 256), dim3(256), 0, s, theta, lws, W, colscale, nin, ncol);
+  hipLaunchKernelGGL(mb_weight_kernel, dim3((ncol + 31) / 32), dim3(256), 0, s, theta, lws, W, colscale, nin, ncol);
   return hipGetLastError();
 }
 hipError_t launch_mb_weight_bwd(const float* theta, const float* colscale, const float* dW, float* dtheta, float* dlws,
                                 int nin, int ncol, int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(mb_weight_bwd_kernel, dim3((ncol + 255) / 256), dim3(256), 0, s, theta, colscale, dW, dtheta, dlws, nin,
+  hipLaunchKernelGGL(mb_weight_bwd_kernel, dim3((ncol + 31) / 32), dim3(256), 0, s, theta, colscale, dW, dtheta, dlws, nin,
                      ncol, accumulate);
   return hipGetLastError();
 }
