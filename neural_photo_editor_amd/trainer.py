@@ -241,6 +241,7 @@ class Trainer:
         self._build_layers(deconv_flip)
         self._alloc()
         self.touched = set()
+        self.update_running = True
 
     # ---------------------------------------------------------------------------------------------
     def _build_params(self, P):
@@ -263,6 +264,17 @@ class Trainer:
             dec += mdcl_names(h, HEAD_SCALES)
         self.groups = {"enc": ParamGroup(torch, enc, shapes, self.dev), "Z": ParamGroup(torch, zp, shapes, self.dev),
                        "dec": ParamGroup(torch, dec, shapes, self.dev)}
+        # batch-norm running averages (not trainable; Lasagne BatchNormLayer alpha = 0.1, App. B.3): what the
+        # deterministic graphs of API.py / sample_IAN.py normalise with after training
+        bn_names = ["bnorm2", "bnorm3", "bnorm4", "bnorm_enc_fc1", "mu_bnorm", "ls_bnorm", "bnorm_dc4"]
+        for dc, ci, co, hw, blk, sc in DEC_STAGES:
+            bn_names += [blk + "bnorm%d" % j for j in range(3)]
+        stat_names = [b + t for b in bn_names for t in (".mean", ".inv_std")]
+        self.stats = ParamGroup(torch, stat_names, shapes, self.dev)
+        for nme in stat_names:
+            self.stats.view(self.stats.p, nme).copy_(torch.from_numpy(np.ascontiguousarray(P[nme], np.float32).ravel()))
+        self.frozen = {k: np.asarray(v, np.float32) for k, v in P.items() if k.startswith("l_IAF_")}
+        self.bn_alpha = 0.1
         self.where = {}
         for gname, g in self.groups.items():
             for nme in g.names:
@@ -344,8 +356,9 @@ class Trainer:
     # ---------------------------------------------------------------------------------------------
     # building blocks
     # ---------------------------------------------------------------------------------------------
-    def _bn_forward(self, bn, y, a, rows, C, stride, gamma, beta, act, count_rows):
-        """batch statistics over this pass (all ranks when exact) -> a = act(bn(y))."""
+    def _bn_forward(self, bn, y, a, rows, C, stride, gamma, beta, act, count_rows, running=None):
+        """batch statistics over this pass (all ranks when exact) -> a = act(bn(y)).  ``running``: name of the
+        BatchNormLayer whose running averages this pass updates (the pass that sees the real minibatch)."""
         k = self.k
         k.colstats(0, y, None, None, None, None, rows, C, stride, 0, self.ws_stats, min(256, rows), bn.sums)
         if self.exact:
@@ -353,6 +366,11 @@ class Trainer:
         bn.count = float(count_rows * (self.comm.world if self.exact else 1))
         k.bn_make_affine(bn.sums, bn.count, BN_EPS, gamma, beta, C, bn.mean, bn.inv_std, bn.scale, bn.shift)
         k.affine(y, a, bn.scale, bn.shift, rows, C, stride, act)
+        if running is not None and self.update_running:
+            for t, cur in ((".mean", bn.mean), (".inv_std", bn.inv_std)):     # r = (1-alpha) r + alpha * batch
+                r = self.stats.view(self.stats.p, running + t)
+                k.axpy(1.0 - self.bn_alpha, r, r, C, 0)
+                k.axpy(self.bn_alpha, cur, r, C, 1)
 
     def _bn_backward(self, bn, dA, a, y, dy, rows, C, stride, act, gname, bname, want_w):
         k = self.k
@@ -400,7 +418,7 @@ class Trainer:
         E["p"], E["loss"], E["dlogits"] = z(n, 3), z(n, 4), z(n, 4)
         return E
 
-    def enc_forward(self, E, x_nchw, targets=(-1, -1), acc_target=0):
+    def enc_forward(self, E, x_nchw, targets=(-1, -1), acc_target=0, running=False):
         """x_nchw: (n,3,64,64) device tensor.  targets: classes whose -log p is recorded in E['loss'][:, 0:2]."""
         k, n = self.k, self.n
         k.nchw_to_nhwc(x_nchw, E["x"], n, 4096, 3, 32)
@@ -409,7 +427,7 @@ class Trainer:
             w, hw = ENC_WIDTHS[i - 1], 64 >> i
             self.layers["enc_conv%d" % i][0].forward(E["a%d" % (i - 1)], n, E["y%d" % i])
             self._bn_forward(E["bn%d" % i], E["y%d" % i], E["a%d" % i], n * hw * hw, w, w, self.P("bnorm%d.gamma" % i),
-                             self.P("bnorm%d.beta" % i), ACT["lrelu"], n * hw * hw)
+                             self.P("bnorm%d.beta" % i), ACT["lrelu"], n * hw * hw, running=("bnorm%d" % i) if running else None)
         k.globalpool(E["a4"], E["feat"], n, 16, 1024, 1024, 1024)
         self.layers["mb"][0].forward(E["feat"], n, E["act"], y_stride=cs(2500))
         row0 = 0
@@ -484,10 +502,10 @@ class Trainer:
         k, n = self.k, self.n
         self.layers["enc_fc1"][0].forward(a4, n, Zs["y_fc1"], y_stride=1024)
         self._bn_forward(Zs["bn_fc1"], Zs["y_fc1"], Zs["f"], n, 1000, 1024, self.P("bnorm_enc_fc1.gamma"), self.P("bnorm_enc_fc1.beta"),
-                         ACT["relu"], n)
+                         ACT["relu"], n, running="bnorm_enc_fc1")
         for nm, ln, bn in (("mu", "enc_mu", "mu_bnorm"), ("ls", "enc_logsigma", "ls_bnorm")):
             self.layers[ln][0].forward(Zs["f"], n, Zs["y_" + nm], y_stride=128)
-            self._bn_forward(Zs["bn_" + nm], Zs["y_" + nm], Zs[nm], n, 100, 128, self.P(bn + ".gamma"), self.P(bn + ".beta"), 0, n)
+            self._bn_forward(Zs["bn_" + nm], Zs["y_" + nm], Zs[nm], n, 100, 128, self.P(bn + ".gamma"), self.P(bn + ".beta"), 0, n, running=bn)
         k.sample(Zs["mu"], Zs["ls"], eps, Zs["z0"], Zs["kl"], n, 100, 128, eps.shape[1])
         k.made_iaf(Zs["z0"], Zs["z"], self.made_w, self.made_b, n, 100, 128)
 
@@ -530,8 +548,9 @@ class Trainer:
         D["dz"] = z(n, 128)
         return D
 
-    def dec_forward(self, D, zbuf):
+    def dec_forward(self, D, zbuf, running=False):
         k, n = self.k, self.n
+        rn = (lambda nme: nme) if running else (lambda nme: None)
         lay = lambda nme: self.layers[nme][0]
         lay("l_dec_fc2").forward(zbuf, n, D["h0"], y_stride=8192, bias=self.fc2_bias, act=ACT["lrelu"])
         h = D["h0"]
@@ -540,15 +559,15 @@ class Trainer:
             rows = n * s * s
             g = lambda j, t: self.P("%sbnorm%d.%s" % (blk, j, t))
             lay(dc).forward(h, n, D[blk + "_x"])
-            self._bn_forward(D[blk + "_bn0"], D[blk + "_x"], D[blk + "_a"], rows, co, co, g(0, "gamma"), g(0, "beta"), ACT["lrelu"], rows)
+            self._bn_forward(D[blk + "_bn0"], D[blk + "_x"], D[blk + "_a"], rows, co, co, g(0, "gamma"), g(0, "beta"), ACT["lrelu"], rows, rn(blk + "bnorm0"))
             lay(blk).forward(D[blk + "_a"], n, D[blk + "_b"])
-            self._bn_forward(D[blk + "_bn1"], D[blk + "_b"], D[blk + "_c"], rows, co, co, g(1, "gamma"), g(1, "beta"), ACT["lrelu"], rows)
+            self._bn_forward(D[blk + "_bn1"], D[blk + "_b"], D[blk + "_c"], rows, co, co, g(1, "gamma"), g(1, "beta"), ACT["lrelu"], rows, rn(blk + "bnorm1"))
             lay(blk + "2").forward(D[blk + "_c"], n, D[blk + "_e"], res=D[blk + "_x"])       # ElemwiseSum (layers.py:415)
-            self._bn_forward(D[blk + "_bn2"], D[blk + "_e"], D[blk + "_h"], rows, co, co, g(2, "gamma"), g(2, "beta"), ACT["lrelu"], rows)
+            self._bn_forward(D[blk + "_bn2"], D[blk + "_e"], D[blk + "_h"], rows, co, co, g(2, "gamma"), g(2, "beta"), ACT["lrelu"], rows, rn(blk + "bnorm2"))
             h = D[blk + "_h"]
         rows = n * 4096
         lay("dec_conv4").forward(h, n, D["y4"])
-        self._bn_forward(D["bn4"], D["y4"], D["h4"], rows, 128, 128, self.P("bnorm_dc4.gamma"), self.P("bnorm_dc4.beta"), ACT["lrelu"], rows)
+        self._bn_forward(D["bn4"], D["y4"], D["h4"], rows, 128, 128, self.P("bnorm_dc4.gamma"), self.P("bnorm_dc4.beta"), ACT["lrelu"], rows, rn("bnorm_dc4"))
         sg = ACT["sigmoid"]
         lay("R").forward(D["h4"], n, D["R"], act=sg)                                          # IAN.py:183-186
         lay("G_a").forward(D["h4"], n, D["Ga"])
@@ -652,10 +671,10 @@ class Trainer:
         self._ensure_passes()
         self.refresh_weights()
         self.X = X
-        self.enc_forward(self.EX, X, targets=(0, -1), acc_target=0)                           # p_X vs p1
+        self.enc_forward(self.EX, X, targets=(0, -1), acc_target=0, running=True)             # p_X vs p1
         self.ZS["eps"] = eps
         self.z_forward(self.ZS, self.EX["a4"], eps)
-        self.dec_forward(self.DZ, self.ZS["z"])                                                # X_hat
+        self.dec_forward(self.DZ, self.ZS["z"], running=True)                                  # X_hat
         self.enc_forward(self.EH, self.DZ["xhat"] if xhat_override is None else xhat_override, targets=(0, 1), acc_target=1)  # p_X_hat
         k.grad_pass(Z, Z.shape[1], 0, self.zgen0, None, 128, n, 100, 0, 0)                     # (n,100) -> padded rows
         k.made_iaf(self.zgen0, self.zgen, self.made_w, self.made_b, n, 100, 128)               # {l_Z_IAF: Z} (:149)
@@ -758,7 +777,24 @@ class Trainer:
         m = self.step("discrim", X, Z, eps)
         return [m[k] for k in ("discrim_g_loss", "discrim_d_loss", "discrim_acc", "pixel_loss", "pixel_acc")]
 
-    # ---- introspection for tests / checkpoints ----------------------------------------------------------
+    # ---- checkpoints (GANcheckpoints.py format, Theano parameter names: train_IAN.py:563-569) -------------
+    def state_dict(self):
+        """Every parameter the inference graph needs, reference layout and names: trainable groups, batch-norm
+        running averages (updated from the real-data pass, alpha 0.1) and the frozen MADE parameters."""
+        out = self.params_numpy()
+        flat = self.stats.p.cpu().numpy()
+        for n, (o, cnt, shape) in self.stats.offsets.items():
+            out[n] = flat[o:o + cnt].reshape(shape).copy()
+        out.update(self.frozen)
+        return out
+
+    def save_weights(self, fname, metadata=None):
+        from . import checkpoints
+        meta = {"learning_rate": self.lr}
+        meta.update(metadata or {})
+        checkpoints.save_weights(fname, self.state_dict(), meta)
+
+    # ---- introspection for tests ------------------------------------------------------------------------
     def grads_numpy(self, gname):
         g = self.groups[gname]
         flat = g.g.cpu().numpy()

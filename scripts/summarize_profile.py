@@ -11,8 +11,10 @@ PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md:
   * FETCH_SIZE and WRITE_SIZE come from separate passes (3 + 2 TCC slots do not fit one pass), unit KiB;
   * on gfx950 FETCH_SIZE counts 128-byte requests of wide coalesced reads as 64 B -> the read side is doubled
     for the 16-B/lane streaming kernels (tapgemm, edge layers); WRITE_SIZE is uncalibrated and left as reported;
-  * derived MfmaUtil is a gfx94x formula -> SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over SIMDs... reported per
-    XCD-accumulated) is compared against GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs instead.
+  * derived MfmaUtil is a gfx94x formula -> SQ_VALU_MFMA_BUSY_CYCLES (SIMD-cycles summed over the chip: exactly
+    64 x #MFMA for v_mfma_f32_32x32x2_f32) is compared against the kernel's cycles x 1024 SIMDs instead, with the
+    kernel's cycles = GRBM_GUI_ACTIVE / 8 (the counter is reported summed over the 8 XCDs: it reads ~8x the
+    duration x clock of the same dispatch).
 """
 from __future__ import annotations
 
@@ -137,7 +139,7 @@ def main():
     if per_kernel:
         md += ["## PMC counters per launch (separate passes; steady-state steps only)", "",
                "FETCH is FETCH_SIZE KiB x 1024 x 2 (gfx950 128-B-request correction), WRITE is WRITE_SIZE KiB x 1024 (uncalibrated).",
-               "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs).", "",
+               "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs).", "",
                "| kernel | grid threads | HBM read MB | HBM write MB | MFMA busy % | wave-cycles: active / wait-inst / wait-any % | LDS bank-conflict % | L2 hit % |",
                "|---|---|---|---|---|---|---|---|"]
         traffic = {}
@@ -146,7 +148,7 @@ def main():
             rd = c.get("FETCH_SIZE", float("nan")) * 1024 * 2
             wr = c.get("WRITE_SIZE", float("nan")) * 1024
             gui = c.get("GRBM_GUI_ACTIVE", 0)
-            mf = 100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui * 1024) if gui else float("nan")
+            mf = 100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui / 8.0 * 1024) if gui else float("nan")
             wc = c.get("SQ_WAVE_CYCLES", 0)
             frac = "%.0f / %.0f / %.0f" % (100 * c.get("SQ_ACTIVE_INST_ANY", 0) / wc, 100 * c.get("SQ_WAIT_INST_ANY", 0) / wc,
                                           100 * c.get("SQ_WAIT_ANY", 0) / wc) if wc else "-"
