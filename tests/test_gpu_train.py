@@ -223,3 +223,23 @@ def torch_conv_features(tw, X):
     x = torch.tensor(X, dtype=torch.float64)
     h1 = F.leaky_relu(F.conv2d(x, tw.P["enc_conv1.W"], tw.P["enc_conv1.b"], stride=2, padding=2), 0.2)
     return F.conv2d(h1, tw.P["enc_conv2.W"], None, stride=2, padding=2)
+
+
+def test_training_loop_end_to_end(setup, tmp_path):
+    """train_IAN.py main-loop equivalent over the real step: 1 epoch, 2 chunks x 2 batches, checkpoint + metrics log."""
+    from neural_photo_editor_amd import train_loop as TL, checkpoints
+    from neural_photo_editor_amd.trainer import Trainer
+    _, _, P = setup
+    tr = Trainer(CFG, P, batch=B)
+    cfg = dict(tr.cfg, batch_size=B, batches_per_chunk=2, max_epochs=1, shuffle=True)
+    imgs = np.uint8((O.make_images(16, seed=77) + 1) * 127.5)
+    wf = str(tmp_path / "IAN.npz")
+    itr = TL.train(cfg, tr, TL.ArrayDataset(imgs), wf, to_device=lambda a: dev(a)[0])
+    assert itr == 4 and tr.groups["dec"].t == 2 and tr.groups["enc"].t == 2 and tr.groups["Z"].t == 4
+    recs = TL.read_records(str(tmp_path / "IANMETRICS.jsonl"))
+    assert len(recs) == 2 and all(np.isfinite(v) for r in recs for v in r["metrics"].values())
+    assert set(recs[0]["metrics"]) == set(TL.GEN_KEYS) | set(TL.DISCRIM_KEYS)
+    with np.load(wf, allow_pickle=True) as f:
+        assert "dec_conv1.W" in f.files and "bnorm2.inv_std" in f.files and "metadata" in f.files
+    _, meta = checkpoints.load_weights(wf, [])
+    assert meta["epoch"] == 0 and meta["itr"] == 4

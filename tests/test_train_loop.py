@@ -1,0 +1,110 @@
+"""CPU tests of the training-loop plumbing (train_IAN.py:357-571 equivalents) and the NPE host-side steps."""
+import json
+import os
+
+import numpy as np
+
+from neural_photo_editor_amd import npe_ops, train_loop as TL
+
+CFG = dict(batch_size=4, batches_per_chunk=3, num_latents=100, update_ratio=1, shuffle=True, max_epochs=3, checkpoint_every_nth=1,
+           learning_rate={0: 0.0002, 1: 0.0001, 2: 0.00005}, decay_rate=0, seed=0)
+
+
+class FakeTrainer:
+    def __init__(self):
+        self.lr, self.calls, self.saved = 0.0002, [], []
+
+    def update_gen(self, X, Z, eps):
+        assert X.shape == (4, 3, 64, 64) and Z.shape == (4, 100) and eps.shape == (4, 100) and X.dtype == np.float32
+        assert -1.0 <= X.min() and X.max() <= 1.0
+        self.calls.append("g")
+        return [1.0, 2.0, 3.0, 4.0, 5.0]
+
+    def update_discrim(self, X, Z, eps):
+        self.calls.append("d")
+        return [6.0, 7.0, 8.0, 9.0, 10.0]
+
+    def save_weights(self, fname, metadata):
+        self.saved.append((fname, dict(metadata)))
+
+
+def dataset(n=30):
+    rs = np.random.RandomState(0)
+    return TL.ArrayDataset(rs.randint(0, 256, (n, 3, 64, 64)).astype(np.uint8))
+
+
+def test_data_loader_chunks_and_seeding():
+    ds = dataset(30)
+    chunks = list(TL.data_loader(CFG, ds, offset=0, shuffle=True, seed=3))
+    assert len(chunks) == 30 // 12 and chunks[0].shape == (12, 3, 64, 64) and chunks[0].dtype == np.float32
+    again = list(TL.data_loader(CFG, ds, offset=0, shuffle=True, seed=3))
+    assert all(np.array_equal(a, b) for a, b in zip(chunks, again))
+    other = list(TL.data_loader(CFG, ds, offset=0, shuffle=True, seed=4))
+    assert not np.array_equal(chunks[0], other[0])
+    perm = np.random.RandomState(3).permutation(30)
+    assert np.array_equal(chunks[0], TL.to_tanh(ds.images[perm[:12]]))           # train_IAN.py:363,371
+    plain = list(TL.data_loader(CFG, ds, offset=2, shuffle=False))
+    assert np.array_equal(plain[0], TL.to_tanh(ds.images[2:14]))
+
+
+def test_learning_rate_schedule():
+    assert TL.learning_rate_for(CFG, 0, 0.0002) == 0.0002          # epoch 0 never changes it (train_IAN.py:442)
+    assert TL.learning_rate_for(CFG, 1, 0.0002) == 0.0001
+    assert TL.learning_rate_for(CFG, 5, 0.0001) == 0.0001
+    c = dict(CFG, learning_rate=0.001, decay_rate=0.1)
+    assert abs(TL.learning_rate_for(c, 2, 0.001) - 0.0009) < 1e-12
+
+
+def test_training_loop_alternation_metrics_checkpoints_resume(tmp_path):
+    tr = FakeTrainer()
+    wf = str(tmp_path / "IAN.npz")
+    itr = TL.train(CFG, tr, dataset(30), wf)
+    assert itr == 3 * 2 * 3                                          # epochs x chunks x batches
+    assert tr.calls == ["g", "d"] * 9                                 # strict alternation across chunks (train_IAN.py:497-504)
+    assert [m["epoch"] for _, m in tr.saved] == [0, 1, 2] and tr.saved[-1][1]["itr"] == 18
+    assert abs(float(tr.saved[1][1]["learning_rate"]) - 0.0001) < 1e-9 and abs(tr.lr - 0.00005) < 1e-12
+    recs = TL.read_records(str(tmp_path / "IANMETRICS.jsonl"))
+    assert len(recs) == 6 and recs[0]["metrics"]["gen_recon_loss"] == 1.0 and recs[0]["metrics"]["discrim_acc"] == 8.0
+    assert "_stamp" in recs[0] and recs[-1]["itr"] == 18
+    # resume: continues after the stored epoch with the stored learning rate, appends to the log
+    tr2 = FakeTrainer()
+    TL.train(CFG, tr2, dataset(30), wf, resume=True, load_metadata={"epoch": 1, "learning_rate": 0.0001})
+    assert [m["epoch"] for _, m in tr2.saved] == [2] and abs(tr2.lr - 0.00005) < 1e-12
+    assert len(TL.read_records(str(tmp_path / "IANMETRICS.jsonl"))) == 8
+
+
+def test_sample_grid_layout():
+    rs = np.random.RandomState(1)
+    sample = lambda z: np.tanh(z[:, :1, None, None] * np.ones((1, 3, 64, 64), np.float32))
+    zfn = lambda x: x.reshape(len(x), -1)[:, :100].astype(np.float32)
+    endpoints = rs.randint(0, 256, (6, 3, 64, 64)).astype(np.uint8)
+    imgs = TL.sample_grid(sample, zfn, endpoints, 100, rs)
+    assert imgs.shape == (54, 3, 64, 64) and imgs.dtype == np.uint8
+    assert np.array_equal(imgs[27], endpoints[0]) and np.array_equal(imgs[35], endpoints[1])   # [endpoint, 7 interpolants, endpoint]
+    Z = TL.interpolation_latents(zfn(TL.to_tanh(endpoints)))
+    assert Z.shape == (21, 100) and np.allclose(Z[0], zfn(TL.to_tanh(endpoints))[0]) and np.allclose(Z[6], zfn(TL.to_tanh(endpoints))[1])
+    grid = TL.tile_grid(imgs)
+    assert grid.shape == (6 * 64, 9 * 64, 3) and np.array_equal(grid[:64, 64:128].transpose(2, 0, 1), imgs[1])
+
+
+def test_npe_host_steps():
+    class M:
+        def imgradRGB(self, x1, y1, x2, y2, rgb, z):
+            assert rgb.shape == (1, 3, 64, 64) and z.shape == (1, 100)
+            return np.ones((1, 100), np.float32)
+
+        def imgrad(self, x1, y1, x2, y2, z):
+            return np.full((1, 100), 2.0, np.float32)
+
+        def sample_at(self, z):
+            return np.full((1, 3, 64, 64), 0.5, np.float32)
+    Z = np.zeros((10, 10), np.float32)
+    Z2 = npe_ops.brush_step(M(), Z, (26, 26, 30, 30), np.zeros((3, 64, 64), np.uint8))
+    assert Z2.shape == (10, 10) and np.allclose(Z2, -0.05 * 5)                   # NPE.py:199-209: weight*grad*(1+(x2-x1))
+    assert np.allclose(npe_ops.lighten_step(M(), Z, (0, 0, 4, 4)), 0.2)
+    recon = np.full((3, 64, 64), 127, np.uint8)
+    im, mask = npe_ops.photo_blend(M(), Z, recon, np.zeros((3, 64, 64), np.float32))
+    delta = 0.5 - npe_ops.to_tanh(recon)
+    assert np.allclose(mask, np.abs(delta).mean(0), atol=1e-5)                   # constant field: the Gaussian leaves it unchanged
+    want = np.uint8(npe_ops.from_tanh(npe_ops.to_tanh(recon) + mask * delta))
+    assert np.abs(im.astype(int) - want.astype(int)).max() <= 1
