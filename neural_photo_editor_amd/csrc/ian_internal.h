@@ -142,6 +142,16 @@ struct MdcHeadArgs {
   signed char dy[48], dx[48];
 };
 hipError_t launch_mdc_head(const MdcHeadArgs& a, int n, int Cin, int Cout, hipStream_t s);
+// few-filter MDCL backward-weight on the VALU; partial: [nblocks][ntaps][2 or 4][Cin] floats
+struct MdcHeadWgradArgs {
+  const float* x;   // layer input, NHWC, pixel stride xs
+  const float* dy;  // gradient wrt the pre-activation output, NHWC, pixel stride dys
+  float* partial;
+  int H, W, xs, dys, ntaps, total_tiles;
+  signed char dy_[48], dx_[48];
+};
+hipError_t launch_mdc_head_wgrad(const MdcHeadWgradArgs& a, int nblocks, int Cin, int Cout, float* dS, int f_rows,
+                                 int f_cols, hipStream_t s);
 // identity-edge gradient hand-over: gd[p,c] (+)= gs[p,coff+c] * act'(y[p,c]) * scale[c]   (NHWC, strides ss / ds)
 hipError_t launch_grad_pass(const float* gs, int ss, int coff, float* gd, const float* y, int ds, const float* scale,
                             long long npix, int C, int act, int accumulate, hipStream_t s);

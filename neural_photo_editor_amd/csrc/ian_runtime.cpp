@@ -1965,6 +1965,34 @@ int ian_layer_backward_weight(ian_layer* l, const float* x, const float* dy, int
   if (!l || !x || !dy || !dparams || n <= 0 || nparams != (int)l->pnumel.size()) return lfail(l, -1, "bad argument to ian_layer_backward_weight");
   hipStream_t st = (hipStream_t)stream;
   const TgLayer& L = l->op.fwd;
+  if (l->is_mdc && mdc_head_eligible(&l->ctx, l->op)) {  // RGB-Beta head: VALU backward-weight, no 16x padded MFMA tile
+    MdcHeadWgradArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = x; a.dy = dy; a.H = L.IH; a.W = L.IW; a.xs = L.Cin; a.dys = round_up(L.Cout, 32); a.ntaps = (int)L.taps.size();
+    a.total_tiles = n * (L.IH / 4) * (L.IW / 16);
+    for (int t = 0; t < a.ntaps; ++t) { a.dy_[t] = (signed char)L.taps[t].dy; a.dx_[t] = (signed char)L.taps[t].dx; }
+    const int nblocks = std::min(a.total_tiles, 512);
+    const int cpad = L.Cout <= 2 ? 2 : 4;
+    const size_t need = (size_t)nblocks * a.ntaps * cpad * L.Cin;
+    if (need > l->partial_cap) {
+      if (l->d_partial) LHIP(l, hipFree(l->d_partial));
+      LHIP(l, hipMalloc((void**)&l->d_partial, need * sizeof(float)));
+      l->partial_cap = need;
+    }
+    a.partial = l->d_partial;
+    LHIP(l, hipMemsetAsync(l->d_dS, 0, l->op.fwd.w_floats * sizeof(float), st));
+    LHIP(l, launch_mdc_head_wgrad(a, nblocks, L.Cin, L.Cout, l->d_dS, L.CoutPad, L.Cin, st));
+    MdcCoeffGrads g;
+    memset(&g, 0, sizeof g);
+    g.d[0] = dparams[1];
+    for (int i = 2; i < nparams; ++i) {
+      const int b = l->mdc_param_branch[i - 1];
+      if (b < 0) g.d1x1 = dparams[i];
+      else g.d[b] = dparams[i];
+    }
+    LHIP(l, launch_mdc_unpack_grad(l->mdc, l->d_dS, dparams[0], g, accumulate, st));
+    return 0;
+  }
   WgSchedule* S;
   int rc = build_wg_schedule(l, n, &S);
   if (rc) return rc;

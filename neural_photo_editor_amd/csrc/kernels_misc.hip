@@ -29,11 +29,12 @@ __device__ __forceinline__ float m_dact(float y, int act) {
 
 // ------------------------------------------------------------------------------------------------
 // enc_conv1 (IAN_simple.py:73-83): x NCHW [n,3,H,W] -> y NHWC [n,H/2,W/2,Cout]; 5x5 s2 p2 correlation.
-// Block = 2 output rows x OW pixels of one image; lane = output channel (coalesced NHWC stores), the
-// 75 filter taps of that channel live in registers, the input patch is broadcast from LDS.
+// Block = 2 output rows x OW pixels of one image.  A lane owns CPL output channels (lane, lane+64, ...: coalesced
+// NHWC stores) whose 75 filter taps live in registers; the input patch value of a tap is the same for the whole
+// wave and is broadcast from LDS, so every LDS read feeds CPL FMAs (the kernel is LDS-issue bound at CPL = 1).
 // ------------------------------------------------------------------------------------------------
 constexpr int C1_ROWS = 2;
-template <int COUT>
+template <int COUT, int CPL>
 __global__ __launch_bounds__(256) void conv1_nchw_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float* __restrict__ y,
@@ -52,26 +53,42 @@ __global__ __launch_bounds__(256) void conv1_nchw_kernel(const float* __restrict
     sm[i] = v;
   }
   __syncthreads();
-  constexpr int GROUPS = 256 / COUT;  // pixel groups per block
-  const int co = threadIdx.x % COUT, grp = threadIdx.x / COUT;
-  float wr[75];
+  constexpr int LPP = COUT / CPL;     // lanes per pixel
+  constexpr int GROUPS = 256 / LPP;   // pixels in flight per block
+  const int co0 = threadIdx.x % LPP, grp = threadIdx.x / LPP;
+  float wr[CPL][75];
 #pragma unroll
-  for (int k = 0; k < 75; ++k) wr[k] = w[k * COUT + co];
-  const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+  for (int j = 0; j < CPL; ++j)
+#pragma unroll
+    for (int k = 0; k < 75; ++k) wr[j][k] = w[k * COUT + co0 + j * LPP];
+  float sc[CPL], sh[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    sc[j] = scale ? scale[co0 + j * LPP] : 1.f;
+    sh[j] = shift ? shift[co0 + j * LPP] : 0.f;
+  }
   const int npix = C1_ROWS * OW;
   for (int pidx = grp; pidx < npix; pidx += GROUPS) {
     const int r = pidx / OW, ox = pidx % OW;
     if (oy0 + r >= OH) break;
-    float acc = 0.f;
+    float acc[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int ky = 0; ky < 5; ++ky) {
         const float* row = sm + (c * PR + 2 * r + ky) * PW + 2 * ox;
 #pragma unroll
-        for (int kx = 0; kx < 5; ++kx) acc = fmaf(row[kx], wr[(c * 5 + ky) * 5 + kx], acc);
+        for (int kx = 0; kx < 5; ++kx) {
+          const float xv = row[kx];
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) acc[j] = fmaf(xv, wr[j][(c * 5 + ky) * 5 + kx], acc[j]);
+        }
       }
-    y[((size_t)(n * OH + oy0 + r) * OW + ox) * COUT + co] = m_act(acc * sc + sh, act);
+    float* dst = y + ((size_t)(n * OH + oy0 + r) * OW + ox) * COUT + co0;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) dst[j * LPP] = m_act(acc[j] * sc[j] + sh[j], act);
   }
 }
 
@@ -81,11 +98,11 @@ hipError_t launch_conv1_nchw(const float* x, const float* w, const float* scale,
   const size_t lds = (size_t)3 * (2 * C1_ROWS + 3) * (W + 4) * sizeof(float);
   dim3 grid((OH + C1_ROWS - 1) / C1_ROWS, n);
   if (Cout == 128)
-    hipLaunchKernelGGL(conv1_nchw_kernel<128>, grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, act);
+    hipLaunchKernelGGL((conv1_nchw_kernel<128, 2>), grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, act);
   else if (Cout == 64)
-    hipLaunchKernelGGL(conv1_nchw_kernel<64>, grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, act);
+    hipLaunchKernelGGL((conv1_nchw_kernel<64, 1>), grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, act);
   else if (Cout == 256)
-    hipLaunchKernelGGL(conv1_nchw_kernel<256>, grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, act);
+    hipLaunchKernelGGL((conv1_nchw_kernel<256, 2>), grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, act);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
@@ -117,19 +134,20 @@ __device__ __forceinline__ int dq_pos_to_lane(int qy, int qx) {
   return (gi >> 1) * 32 + l5;
 }
 
+constexpr int DQ_NW = 8;  // waves per block: the scalar filter loads of one wave hide behind the other waves' FMAs
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void deconv_out_nchw_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(DQ_NW * 64) void deconv_out_nchw_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float* __restrict__ y,
                                                               int H, int W, int act) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int PS = CIN + 4;   // padded pixel stride
-  constexpr int CW = CIN / 4;   // channels per wave
+  constexpr int CW = CIN / DQ_NW;  // channels per wave
   const int tiles_x = W >> 3;
   const int n = blockIdx.y, ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
   const int iy0 = ty * 8 - 1, ix0 = tx * 8 - 1;
   // stage 10x10 input pixels x CIN
-  for (int i = threadIdx.x; i < 100 * (CIN / 4); i += 256) {
+  for (int i = threadIdx.x; i < 100 * (CIN / 4); i += DQ_NW * 64) {
     const int pix = i / (CIN / 4), c4 = (i % (CIN / 4)) * 4;
     const int iy = iy0 + pix / 10, ix = ix0 + pix % 10;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -181,6 +199,7 @@ __global__ __launch_bounds__(256) void deconv_out_nchw_kernel(const float* __res
     for (int co = 0; co < COUT; ++co) sm[((wave * 4 + k) * COUT + co) * 64 + lane] = acc[k][co];
   __syncthreads();
   const int OH = 2 * H, OW = 2 * W;
+  if (threadIdx.x >= 256) return;
   const int oyl = threadIdx.x >> 4, oxl = threadIdx.x & 15;  // 16x16 output tile, rows of 16 consecutive pixels
   const int cls = (oyl & 1) * 2 + (oxl & 1);
   const int src = dq_pos_to_lane(oyl >> 1, oxl >> 1);
@@ -189,7 +208,7 @@ __global__ __launch_bounds__(256) void deconv_out_nchw_kernel(const float* __res
   for (int co = 0; co < COUT; ++co) {
     float v = 0.f;
 #pragma unroll
-    for (int wv = 0; wv < 4; ++wv) v += sm[((wv * 4 + cls) * COUT + co) * 64 + src];
+    for (int wv = 0; wv < DQ_NW; ++wv) v += sm[((wv * 4 + cls) * COUT + co) * 64 + src];
     const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
     y[((size_t)(n * COUT + co) * OH + oy) * OW + ox] = m_act(v * sc + sh, act);
   }
@@ -201,10 +220,10 @@ static hipError_t launch_deconv_out_cin(const float* x, const float* w, const fl
   dim3 grid((H / 8) * (W / 8), n);
   const size_t lds = (size_t)100 * (CIN + 4) * sizeof(float);
   switch (Cout) {
-    case 1: hipLaunchKernelGGL((deconv_out_nchw_kernel<CIN, 1>), grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, act); break;
-    case 2: hipLaunchKernelGGL((deconv_out_nchw_kernel<CIN, 2>), grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, act); break;
-    case 3: hipLaunchKernelGGL((deconv_out_nchw_kernel<CIN, 3>), grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, act); break;
-    case 4: hipLaunchKernelGGL((deconv_out_nchw_kernel<CIN, 4>), grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, act); break;
+    case 1: hipLaunchKernelGGL((deconv_out_nchw_kernel<CIN, 1>), grid, dim3(DQ_NW * 64), lds, s, x, w, scale, shift, y, H, W, act); break;
+    case 2: hipLaunchKernelGGL((deconv_out_nchw_kernel<CIN, 2>), grid, dim3(DQ_NW * 64), lds, s, x, w, scale, shift, y, H, W, act); break;
+    case 3: hipLaunchKernelGGL((deconv_out_nchw_kernel<CIN, 3>), grid, dim3(DQ_NW * 64), lds, s, x, w, scale, shift, y, H, W, act); break;
+    case 4: hipLaunchKernelGGL((deconv_out_nchw_kernel<CIN, 4>), grid, dim3(DQ_NW * 64), lds, s, x, w, scale, shift, y, H, W, act); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -455,14 +474,15 @@ hipError_t launch_dact_nchw(float* g, const float* y, const float* scale, int n,
 // ------------------------------------------------------------------------------------------------
 constexpr int MH_HALO = 4, MH_TH = 4, MH_TW = 16, MH_PH = MH_TH + 2 * MH_HALO, MH_PW = MH_TW + 2 * MH_HALO;
 
+constexpr int MH_NW = 8;  // waves per block (one block per CU: 152 KB of LDS)
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void mdc_head_kernel(MdcHeadArgs a) {
+__global__ __launch_bounds__(MH_NW * 64) void mdc_head_kernel(MdcHeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  constexpr int PS = CIN + 4, CW = CIN / 4;
+  constexpr int PS = CIN + 4, CW = CIN / MH_NW;
   const int tiles_x = a.W / MH_TW;
   const int n = blockIdx.y, ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
   const int iy0 = ty * MH_TH - MH_HALO, ix0 = tx * MH_TW - MH_HALO;
-  for (int i = threadIdx.x; i < MH_PH * MH_PW * (CIN / 4); i += 256) {
+  for (int i = threadIdx.x; i < MH_PH * MH_PW * (CIN / 4); i += MH_NW * 64) {
     const int pix = i / (CIN / 4), c4 = (i % (CIN / 4)) * 4;
     const int iy = iy0 + pix / MH_PW, ix = ix0 + pix % MH_PW;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -506,13 +526,15 @@ __global__ __launch_bounds__(256) void mdc_head_kernel(MdcHeadArgs a) {
   for (int co = 0; co < COUT; ++co) sm[(wave * COUT + co) * 64 + lane] = acc[co];
   __syncthreads();
   // thread -> (pixel, co): consecutive threads write consecutive channels of a pixel
-  for (int i = threadIdx.x; i < 64 * COUT; i += 256) {
+  for (int i = threadIdx.x; i < 64 * COUT; i += MH_NW * 64) {
     const int co = i % COUT, pl = i / COUT;  // pl: pixel in row-major tile order
     const int py = pl / MH_TW, px = pl % MH_TW;
     // inverse of the lane map: row py = group (half = py>>1, g1 = py&1), column px = position
     const int gl = (py & 1) ? (px < 8 ? px + 4 : (px < 12 ? px + 8 : px + 16)) : (px < 4 ? px : (px < 8 ? px + 8 : px + 12));
     const int src = (py >> 1) * 32 + gl;
-    float v = sm[(0 * COUT + co) * 64 + src] + sm[(1 * COUT + co) * 64 + src] + sm[(2 * COUT + co) * 64 + src] + sm[(3 * COUT + co) * 64 + src];
+    float v = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < MH_NW; ++wv) v += sm[(wv * COUT + co) * 64 + src];
     const size_t pix = (size_t)(n * a.H + ty * MH_TH + py) * a.W + tx * MH_TW + px;
     const size_t off = pix * a.ys[co] + a.yc[co];
     if (a.res[co]) v += a.res[co][off];
@@ -534,7 +556,7 @@ hipError_t launch_mdc_head(const MdcHeadArgs& a, int n, int Cin, int Cout, hipSt
       if (e != hipSuccess) return e;                                                                              \
       attr = true;                                                                                                \
     }                                                                                                             \
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                                            \
+    hipLaunchKernelGGL(k, grid, dim3(MH_NW * 64), lds, s, a);                                                     \
     return hipGetLastError();                                                                                     \
   }
   if (Cin == 128) {
@@ -551,6 +573,112 @@ hipError_t launch_mdc_head(const MdcHeadArgs& a, int n, int Cin, int Cout, hipSt
   }
 #undef MH_LAUNCH
   return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward-weight of a few-filter MDCL (RGB-Beta head, train_IAN.py:253-259 T.grad wrt R/G_a/B_a weights):
+//   dS[t][co][ci] = sum_pixels dY[p][co] * X[p + d_t][ci],   co < COUT <= 4.
+// On the MFMA path the 2 filters pad to a 32-wide tile (16x wasted work, 1.7 ms per layer at 128 images).  Here:
+// persistent blocks walk 4x16 pixel tiles (input tile + 4-pixel halo and the dY tile in LDS), a thread owns one
+// input channel and every NG-th tap, accumulates in registers over all its tiles and writes one partial
+// [tap][co][ci]; head_wgrad_reduce sums the partials in block order (reproducible) into the slab layout.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+__global__ __launch_bounds__(512) void mdc_head_wgrad_kernel(MdcHeadWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int NG = 512 / CIN, MAXT = (48 + NG - 1) / NG;
+  float* xt = sm;                                 // [MH_PH*MH_PW][CIN]
+  float* dyt = sm + MH_PH * MH_PW * CIN;          // [64][COUT]
+  const int ci = threadIdx.x % CIN, g = threadIdx.x / CIN;
+  float acc[MAXT][COUT];
+#pragma unroll
+  for (int k = 0; k < MAXT; ++k)
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[k][co] = 0.f;
+  const int tiles_x = a.W / MH_TW, tiles_per_img = (a.H / MH_TH) * tiles_x;
+  for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+    const int n = tile / tiles_per_img, tr = tile % tiles_per_img;
+    const int ty = tr / tiles_x, tx = tr % tiles_x;
+    const int iy0 = ty * MH_TH - MH_HALO, ix0 = tx * MH_TW - MH_HALO;
+    __syncthreads();  // the previous tile is fully consumed
+    for (int i = threadIdx.x; i < MH_PH * MH_PW * (CIN / 4); i += 512) {
+      const int pix = i / (CIN / 4), c4 = (i % (CIN / 4)) * 4;
+      const int iy = iy0 + pix / MH_PW, ix = ix0 + pix % MH_PW;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+        v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.xs + c4);
+      *reinterpret_cast<float4*>(xt + pix * CIN + c4) = v;
+    }
+    for (int i = threadIdx.x; i < 64 * COUT; i += 512) {
+      const int p = i / COUT, co = i % COUT;
+      dyt[i] = a.dy[((size_t)(n * a.H + ty * MH_TH + p / MH_TW) * a.W + tx * MH_TW + p % MH_TW) * a.dys + co];
+    }
+    __syncthreads();
+    for (int p = 0; p < 64; ++p) {
+      float dv[COUT];
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) dv[co] = dyt[p * COUT + co];  // broadcast
+      const int py = p / MH_TW + MH_HALO, px = p % MH_TW + MH_HALO;
+#pragma unroll
+      for (int k = 0; k < MAXT; ++k) {
+        const int ti = g + k * NG;
+        if (ti < a.ntaps) {
+          const float xv = xt[((py + a.dy_[ti]) * MH_PW + px + a.dx_[ti]) * CIN + ci];
+#pragma unroll
+          for (int co = 0; co < COUT; ++co) acc[k][co] = fmaf(dv[co], xv, acc[k][co]);
+        }
+      }
+    }
+  }
+  float* out = a.partial + (size_t)blockIdx.x * a.ntaps * COUT * CIN;
+#pragma unroll
+  for (int k = 0; k < MAXT; ++k) {
+    const int ti = g + k * NG;
+    if (ti < a.ntaps)
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) out[((size_t)ti * COUT + co) * CIN + ci] = acc[k][co];
+  }
+}
+
+// dS[(t*f_rows + co)*f_cols + ci] = sum_b partial[b][t][co][ci]
+__global__ __launch_bounds__(256) void head_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int ntaps,
+                                                                int COUT, int CIN, float* __restrict__ dS, int f_rows,
+                                                                int f_cols) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int per = ntaps * COUT * CIN;
+  if (i >= per) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * per + i];
+  const int ci = i % CIN, co = (i / CIN) % COUT, t = i / (CIN * COUT);
+  dS[((size_t)t * f_rows + co) * f_cols + ci] = s;
+}
+
+hipError_t launch_mdc_head_wgrad(const MdcHeadWgradArgs& a, int nblocks, int Cin, int Cout, float* dS, int f_rows,
+                                 int f_cols, hipStream_t s) {
+  if (Cout < 1 || Cout > 4 || (a.H % MH_TH) || (a.W % MH_TW) || a.ntaps > 48) return hipErrorInvalidValue;
+  const int cpad = Cout <= 2 ? 2 : 4;
+  const size_t lds = ((size_t)MH_PH * MH_PW * Cin + 64 * cpad) * sizeof(float);
+#define MW_LAUNCH(CI, CO)                                                                                         \
+  {                                                                                                               \
+    static bool attr = false;                                                                                     \
+    auto k = mdc_head_wgrad_kernel<CI, CO>;                                                                       \
+    if (!attr) {                                                                                                  \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return e;                                                                              \
+      attr = true;                                                                                                \
+    }                                                                                                             \
+    hipLaunchKernelGGL(k, dim3(nblocks), dim3(512), lds, s, a);                                                   \
+  }
+  if (Cin == 128 && Cout <= 2) MW_LAUNCH(128, 2)
+  else if (Cin == 128) MW_LAUNCH(128, 4)
+  else if (Cin == 64 && Cout <= 2) MW_LAUNCH(64, 2)
+  else if (Cin == 64) MW_LAUNCH(64, 4)
+  else return hipErrorInvalidValue;
+#undef MW_LAUNCH
+  const int per = a.ntaps * cpad * Cin;
+  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((per + 255) / 256), dim3(256), 0, s, a.partial, nblocks, a.ntaps, cpad, Cin,
+                     dS, f_rows, f_cols);
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

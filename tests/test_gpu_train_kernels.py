@@ -50,6 +50,10 @@ CASES = [
     ("mdc", dict(cin=32, cout=32, h=16, scales=[0, 2])), ("mdc", dict(cin=64, cout=64, h=8, scales=[0, 2, 3])),
     ("mdc", dict(cin=32, cout=2, h=32, scales=[2, 3, 4])), ("mdc", dict(cin=2, cout=2, h=32, scales=[2, 3, 4])),
     ("mdc", dict(cin=4, cout=2, h=32, scales=[2, 3, 4])),
+    # few-filter layers wide enough for the VALU head kernels (forward: mdc_head_kernel, backward-weight:
+    # mdc_head_wgrad_kernel) instead of the padded MFMA tiles
+    ("mdc", dict(cin=128, cout=2, h=16, scales=[2, 3, 4])), ("mdc", dict(cin=64, cout=2, h=32, scales=[0, 2])),
+    ("mdc", dict(cin=128, cout=3, h=16, scales=[2, 3, 4])),
 ]
 
 
