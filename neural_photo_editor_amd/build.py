@@ -37,13 +37,33 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link libian.so. Returns the library path."""
-    dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP):
+def _fresh(dig):
+    if os.path.exists(LIB) and os.path.exists(STAMP):
         with open(STAMP) as fh:
-            if fh.read().strip() == dig:
-                return LIB
+            return fh.read().strip() == dig
+    return False
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link libian.so. Returns the library path.
+    Safe to call from several processes at once (one rank per GPU): the build is serialised by a file lock and the
+    late comers find a fresh library."""
+    import fcntl
+    dig = _digest()
+    if not force and _fresh(dig):
+        return LIB
+    lock = open(os.path.join(HERE, ".libian.lock"), "w")
+    try:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and _fresh(dig):
+            return LIB
+        return _build_locked(dig, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(dig, verbose):
     hipcc = _hipcc()
     objs = []
     bdir = os.path.join(HERE, "build")

@@ -535,6 +535,7 @@ __global__ __launch_bounds__(MH_NW * 64) void mdc_head_kernel(MdcHeadArgs a) {
     float v = 0.f;
 #pragma unroll
     for (int wv = 0; wv < MH_NW; ++wv) v += sm[(wv * COUT + co) * 64 + src];
+    if (!a.y[co]) continue;  // padding slot of the filter table
     const size_t pix = (size_t)(n * a.H + ty * MH_TH + py) * a.W + tx * MH_TW + px;
     const size_t off = pix * a.ys[co] + a.yc[co];
     if (a.res[co]) v += a.res[co][off];
@@ -543,8 +544,14 @@ __global__ __launch_bounds__(MH_NW * 64) void mdc_head_kernel(MdcHeadArgs a) {
   }
 }
 
-hipError_t launch_mdc_head(const MdcHeadArgs& a, int n, int Cin, int Cout, hipStream_t s) {
-  if (Cout < 1 || Cout > MH_MAXCO || (a.H % MH_TH) || (a.W % MH_TW) || a.ntaps > 48) return hipErrorInvalidValue;
+hipError_t launch_mdc_head(const MdcHeadArgs& args, int n, int Cin, int Cout, hipStream_t s) {
+  if (Cout < 1 || Cout > MH_MAXCO || (args.H % MH_TH) || (args.W % MH_TW) || args.ntaps > 48) return hipErrorInvalidValue;
+  MdcHeadArgs a = args;
+  for (int co = Cout; co < MH_MAXCO; ++co) {  // the kernel is instantiated for 2/4/6/8 filters: pad with no-op slots
+    a.w[co] = a.w[0];
+    a.y[co] = nullptr;
+    a.res[co] = nullptr;
+  }
   dim3 grid((a.H / MH_TH) * (a.W / MH_TW), n);
   const size_t lds = (size_t)MH_PH * MH_PW * (Cin + 4) * sizeof(float);
 #define MH_LAUNCH(CI, CO)                                                                                         \
