@@ -603,6 +603,15 @@ __global__ __launch_bounds__(512) void mdc_head_wgrad_kernel(MdcHeadWgradArgs a)
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[k][co] = 0.f;
   const int tiles_x = a.W / MH_TW, tiles_per_img = (a.H / MH_TH) * tiles_x;
+  // LDS offset of every tap this thread owns (slots past the tap list point at the centre pixel: they accumulate
+  // a harmless value that is never stored), hoisted out of the pixel loop: no branches, no scalar loads inside
+  int off[MAXT];
+#pragma unroll
+  for (int k = 0; k < MAXT; ++k) {
+    const int ti = g + k * NG;
+    off[k] = (ti < a.ntaps) ? ((int)a.dy_[ti] * MH_PW + (int)a.dx_[ti]) * CIN : 0;
+  }
+  const int kmax = (a.ntaps + NG - 1) / NG;  // uniform: k slots in use
   for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
     const int n = tile / tiles_per_img, tr = tile % tiles_per_img;
     const int ty = tr / tiles_x, tx = tr % tiles_x;
@@ -621,20 +630,21 @@ __global__ __launch_bounds__(512) void mdc_head_wgrad_kernel(MdcHeadWgradArgs a)
       dyt[i] = a.dy[((size_t)(n * a.H + ty * MH_TH + p / MH_TW) * a.W + tx * MH_TW + p % MH_TW) * a.dys + co];
     }
     __syncthreads();
+#pragma unroll 2
     for (int p = 0; p < 64; ++p) {
       float dv[COUT];
 #pragma unroll
       for (int co = 0; co < COUT; ++co) dv[co] = dyt[p * COUT + co];  // broadcast
-      const int py = p / MH_TW + MH_HALO, px = p % MH_TW + MH_HALO;
+      const float* xp = xt + ((p / MH_TW + MH_HALO) * MH_PW + p % MH_TW + MH_HALO) * CIN + ci;
+      float xv[MAXT];
 #pragma unroll
-      for (int k = 0; k < MAXT; ++k) {
-        const int ti = g + k * NG;
-        if (ti < a.ntaps) {
-          const float xv = xt[((py + a.dy_[ti]) * MH_PW + px + a.dx_[ti]) * CIN + ci];
+      for (int k = 0; k < MAXT; ++k)
+        if (k < kmax) xv[k] = xp[off[k]];
 #pragma unroll
-          for (int co = 0; co < COUT; ++co) acc[k][co] = fmaf(dv[co], xv, acc[k][co]);
-        }
-      }
+      for (int k = 0; k < MAXT; ++k)
+        if (k < kmax)
+#pragma unroll
+          for (int co = 0; co < COUT; ++co) acc[k][co] = fmaf(dv[co], xv[k], acc[k][co]);
     }
   }
   float* out = a.partial + (size_t)blockIdx.x * a.ntaps * COUT * CIN;
