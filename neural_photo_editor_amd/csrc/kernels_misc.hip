@@ -92,11 +92,79 @@ __global__ __launch_bounds__(256) void conv1_nchw_kernel(const float* __restrict
   }
 }
 
+// MFMA form of enc_conv1 for 64-pixel-wide images: the 75-deep contraction (3 channels x 5x5 taps, padded to 76) of
+// 64 output pixels x 32 channels per wave runs on v_mfma_f32_32x32x2_f32 (exact fp32).  The im2col operand never
+// exists: a lane reads its patch element straight from the zero-padded LDS image with a compile-time offset per k;
+// the wave's 76x32 filter block lives in 38 registers.  Same block tile as the VALU kernel (2 output rows).
+typedef float c1_f32x16 __attribute__((ext_vector_type(16)));
+template <int COUT>
+__global__ __launch_bounds__(256) void conv1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ y,
+                                                         int H, int act) {
+  constexpr int W = 64, OW = 32, PW = W + 4, PR = 2 * C1_ROWS + 3;
+  __shared__ float sm[3 * PR * PW];
+  const int OH = H >> 1;
+  const int n = blockIdx.y, oy0 = blockIdx.x * C1_ROWS;
+  for (int i = threadIdx.x; i < 3 * PR * PW; i += 256) {
+    const int c = i / (PR * PW), r = (i / PW) % PR, col = i % PW;
+    const int iy = 2 * oy0 - 2 + r, ix = col - 2;
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[((size_t)(n * 3 + c) * H + iy) * W + ix];
+    sm[i] = v;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  for (int cg = wave; cg < COUT / 32; cg += 4) {
+    float wr[38];
+#pragma unroll
+    for (int kk = 0; kk < 38; ++kk) {
+      const int k = 2 * kk + half;
+      wr[kk] = (k < 75) ? w[k * COUT + cg * 32 + l31] : 0.f;
+    }
+    __syncthreads();  // (first pass) the staged image is visible
+    c1_f32x16 acc[C1_ROWS];
+#pragma unroll
+    for (int i = 0; i < C1_ROWS; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 38; ++kk) {
+      // k -> (c, ky, kx) -> offset in the padded image; k = 75 is padding (zero weight, any valid address)
+      const int k0 = 2 * kk, k1 = (2 * kk + 1 < 75) ? 2 * kk + 1 : 74;
+      const int o0 = ((k0 / 25) * PR + (k0 % 25) / 5) * PW + k0 % 5;
+      const int o1 = ((k1 / 25) * PR + (k1 % 25) / 5) * PW + k1 % 5;
+      const int o = half ? o1 : o0;
+#pragma unroll
+      for (int i = 0; i < C1_ROWS; ++i) {
+        const float a = sm[o + (2 * i) * PW + 2 * l31];
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr[kk], acc[i], 0, 0, 0);
+      }
+    }
+    // C layout: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*half (pixel ox)
+    const int c = cg * 32 + l31;
+    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < C1_ROWS; ++i) {
+      if (oy0 + i >= OH) break;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ox = (r & 3) + 8 * (r >> 2) + 4 * half;
+        y[((size_t)(n * OH + oy0 + i) * OW + ox) * COUT + c] = m_act(acc[i][r] * sc + sh, act);
+      }
+    }
+  }
+}
+
 hipError_t launch_conv1_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y, int n,
                              int H, int W, int Cout, int act, hipStream_t s) {
   const int OH = H / 2;
   const size_t lds = (size_t)3 * (2 * C1_ROWS + 3) * (W + 4) * sizeof(float);
   dim3 grid((OH + C1_ROWS - 1) / C1_ROWS, n);
+  if (W == 64 && Cout == 128) {
+    hipLaunchKernelGGL((conv1_mfma_kernel<128>), grid, dim3(256), 0, s, x, w, scale, shift, y, H, act);
+    return hipGetLastError();
+  }
   if (Cout == 128)
     hipLaunchKernelGGL((conv1_nchw_kernel<128, 2>), grid, dim3(256), lds, s, x, w, scale, shift, y, H, W, act);
   else if (Cout == 64)

@@ -21,7 +21,6 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-import os
 
 import numpy as np
 
@@ -227,8 +226,6 @@ class Trainer:
         self.dev = torch.device(device)
         mod = config_loader.load_config(config_path)
         self.cfg = dict(mod.cfg)
-        for k in ("l_IAF_mu", "l_Z_IAF"):
-            pass
         c = self.cfg
         self.n = int(batch)                      # per-rank batch
         self.comm = comm or Comm()
