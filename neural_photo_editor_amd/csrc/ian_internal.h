@@ -142,6 +142,18 @@ struct MdcHeadArgs {
   signed char dy[48], dx[48];
 };
 hipError_t launch_mdc_head(const MdcHeadArgs& a, int n, int Cin, int Cout, hipStream_t s);
+// MDCL with <= 4 real input channels on the VALU (forward of G_b / B_b, backward-data of every 2-filter head layer)
+struct MdcThinArgs {
+  const float* x;  // NHWC, pixel stride xs (>= 4 floats readable per pixel)
+  const float* w;  // slab [tap][CoutPad][CinPad]
+  const float* res;
+  const float* scale;
+  const float* shift;
+  float* y;        // NHWC, pixel stride ys
+  int n, H, W, xs, ys, Cout, CoutPad, CinPad, ntaps, act;
+  signed char dy[48], dx[48];
+};
+hipError_t launch_mdc_thin(const MdcThinArgs& a, hipStream_t s);
 // few-filter MDCL backward-weight on the VALU; partial: [nblocks][ntaps][2 or 4][Cin] floats
 struct MdcHeadWgradArgs {
   const float* x;   // layer input, NHWC, pixel stride xs

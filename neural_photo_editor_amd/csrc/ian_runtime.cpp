@@ -794,6 +794,23 @@ int run_tapgemm(ian_handle* h, TgLayer& L, int nimg, const float* x, float* y, i
   return 0;
 }
 
+// thin MDCL: <= 4 real input channels (forward of G_b/B_b; backward-data form of every 2-filter head layer)
+bool mdc_thin_eligible(const ian_handle* h, const TgLayer& L) {
+  if (!h->opt.mdc_head || !L.valid || L.cin_real > 4 || L.classes.size() != 1 || L.taps.size() > 36) return false;
+  if (L.si != 1 || L.so != 1 || L.by != 0 || L.bx != 0 || L.QH != L.IH || L.QW != L.IW) return false;
+  if (L.Cout > 4) return false;  // wide outputs (backward-data of the 2-filter heads) measured 10x slower here than on tapgemm
+  for (auto& t : L.taps)
+    if (t.dy < -64 || t.dy > 64 || t.dx < -64 || t.dx > 64) return false;
+  return true;
+}
+
+void mdc_thin_fill(MdcThinArgs& a, const TgLayer& L, const float* x, int xs, float* y, int ys, int n) {
+  memset(&a, 0, sizeof a);
+  a.x = x; a.w = L.d_w; a.y = y; a.n = n; a.H = L.IH; a.W = L.IW; a.xs = xs; a.ys = ys; a.Cout = L.Cout;
+  a.CoutPad = L.CoutPad; a.CinPad = L.Cin; a.ntaps = (int)L.taps.size();
+  for (int t = 0; t < a.ntaps; ++t) { a.dy[t] = (signed char)L.taps[t].dy; a.dx[t] = (signed char)L.taps[t].dx; }
+}
+
 bool mdc_head_eligible(const ian_handle* h, const OpPlan& op) {
   const TgLayer& L = op.fwd;
   if (!h->opt.mdc_head || L.Cout > 4 || (L.Cin != 128 && L.Cin != 64) || L.cin_real != L.Cin) return false;
@@ -888,6 +905,13 @@ int run_op_fwd(ian_handle* h, OpPlan& op, int n, hipStream_t st) {
     case IAN_OP_MDC3:
       if (op.d.src2 >= 0) res = h->slots[op.d.src2].d;
       if (mdc_head_eligible(h, op)) return run_mdc_head_group(h, op, n, st);
+      if (mdc_thin_eligible(h, op.fwd)) {
+        MdcThinArgs a;
+        mdc_thin_fill(a, op.fwd, src.d, src.cs, dst.d, dst.cs, n);
+        a.res = res; a.scale = op.d_scale; a.shift = op.d_shift; a.act = op.d.act;
+        HIPCHK(h, launch_mdc_thin(a, st));
+        return 0;
+      }
       return run_tapgemm(h, op.fwd, n, src.d, dst.d, dst.cs, fwd_epi(op, res), st);
     case IAN_OP_DENSE:
       return run_tapgemm(h, op.fwd, n, src.d, dst.d, (int)dst.per_image(), fwd_epi(op, nullptr), st);
@@ -1490,7 +1514,7 @@ int ian_autotune(ian_handle* h, int32_t n, int32_t what, void* stream) {
   if (what & 1) {
     for (auto& op : h->ops) {
       if (!op.fwd.valid) continue;
-      if (op.d.kind == IAN_OP_MDC3 && mdc_head_eligible(h, op)) continue;  // runs on the VALU head kernel, nothing to tune
+      if (op.d.kind == IAN_OP_MDC3 && (mdc_head_eligible(h, op) || mdc_thin_eligible(h, op.fwd))) continue;  // VALU kernels: nothing to tune
       if (!have(op.d.src, false) || !have(op.d.src2, false) || !have(op.d.dst, false)) {
         h->prof = prof;
         return fail(h, -6, "ian_autotune: run a forward call with batch >= %d first (op '%s' has no activations)", n, op.name.c_str());
@@ -1946,6 +1970,13 @@ int ian_layer_forward(ian_layer* l, const float* x, int32_t n, float* y, int32_t
     LHIP(l, launch_mdc_head(a, n, L.Cin, L.Cout, (hipStream_t)stream));
     return 0;
   }
+  if (l->op.d.kind == IAN_OP_MDC3 && mdc_thin_eligible(&l->ctx, l->op.fwd)) {
+    MdcThinArgs a;
+    mdc_thin_fill(a, l->op.fwd, x, l->op.fwd.Cin, y, y_stride, n);
+    a.res = res; a.shift = bias; a.act = act;
+    LHIP(l, launch_mdc_thin(a, (hipStream_t)stream));
+    return 0;
+  }
   return run_tapgemm(&l->ctx, l->op.fwd, n, x, y, y_stride, e, (hipStream_t)stream);
 }
 
@@ -1957,6 +1988,13 @@ int ian_layer_backward_data(ian_layer* l, const float* dy, int32_t n, float* dx,
   e.scale = nullptr; e.shift = nullptr; e.res = accumulate ? dx : nullptr; e.yfwd = nullptr; e.act = IAN_ACT_NONE;
   e.scale_period = 0; e.mode = TG_EPI_BWD;
   if (dx_stride <= 0) dx_stride = round_up(l->op.bwd.Cout, 32);
+  if (l->op.d.kind == IAN_OP_MDC3 && mdc_thin_eligible(&l->ctx, l->op.bwd)) {
+    MdcThinArgs a;
+    mdc_thin_fill(a, l->op.bwd, dy, l->op.bwd.Cin, dx, dx_stride, n);
+    a.res = accumulate ? dx : nullptr;
+    LHIP(l, launch_mdc_thin(a, (hipStream_t)stream));
+    return 0;
+  }
   return run_tapgemm(&l->ctx, l->op.bwd, n, dy, dx, dx_stride, e, (hipStream_t)stream);
 }
 
@@ -1965,7 +2003,10 @@ int ian_layer_backward_weight(ian_layer* l, const float* x, const float* dy, int
   if (!l || !x || !dy || !dparams || n <= 0 || nparams != (int)l->pnumel.size()) return lfail(l, -1, "bad argument to ian_layer_backward_weight");
   hipStream_t st = (hipStream_t)stream;
   const TgLayer& L = l->op.fwd;
-  if (l->is_mdc && mdc_head_eligible(&l->ctx, l->op)) {  // RGB-Beta head: VALU backward-weight, no 16x padded MFMA tile
+  const bool thin_in = l->is_mdc && l->ctx.opt.mdc_head && L.cin_real <= 4 && L.Cout <= 4 && (L.IH % 4) == 0 && (L.IW % 16) == 0 &&
+                       L.taps.size() <= 48 && mdc_thin_eligible(&l->ctx, L);
+  if (l->is_mdc && (mdc_head_eligible(&l->ctx, l->op) || thin_in)) {  // RGB-Beta head: VALU backward-weight, no padded MFMA tile
+    const int kcin = thin_in ? 4 : L.Cin;  // thin layers: the 2-4 real channels (+ zero padding) of the 32-float pixel row
     MdcHeadWgradArgs a;
     memset(&a, 0, sizeof a);
     a.x = x; a.dy = dy; a.H = L.IH; a.W = L.IW; a.xs = L.Cin; a.dys = round_up(L.Cout, 32); a.ntaps = (int)L.taps.size();
@@ -1973,7 +2014,7 @@ int ian_layer_backward_weight(ian_layer* l, const float* x, const float* dy, int
     for (int t = 0; t < a.ntaps; ++t) { a.dy_[t] = (signed char)L.taps[t].dy; a.dx_[t] = (signed char)L.taps[t].dx; }
     const int nblocks = std::min(a.total_tiles, 512);
     const int cpad = L.Cout <= 2 ? 2 : 4;
-    const size_t need = (size_t)nblocks * a.ntaps * cpad * L.Cin;
+    const size_t need = (size_t)nblocks * a.ntaps * cpad * kcin;
     if (need > l->partial_cap) {
       if (l->d_partial) LHIP(l, hipFree(l->d_partial));
       LHIP(l, hipMalloc((void**)&l->d_partial, need * sizeof(float)));
@@ -1981,7 +2022,7 @@ int ian_layer_backward_weight(ian_layer* l, const float* x, const float* dy, int
     }
     a.partial = l->d_partial;
     LHIP(l, hipMemsetAsync(l->d_dS, 0, l->op.fwd.w_floats * sizeof(float), st));
-    LHIP(l, launch_mdc_head_wgrad(a, nblocks, L.Cin, L.Cout, l->d_dS, L.CoutPad, L.Cin, st));
+    LHIP(l, launch_mdc_head_wgrad(a, nblocks, kcin, L.Cout, l->d_dS, L.CoutPad, L.Cin, st));
     MdcCoeffGrads g;
     memset(&g, 0, sizeof g);
     g.d[0] = dparams[1];

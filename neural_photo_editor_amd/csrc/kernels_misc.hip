@@ -2,6 +2,8 @@
 // These are the HBM/latency-bound pieces (SURVEY "hard parts": Cout=3 / Cin=3 layers waste MFMA tiles),
 // written as VALU kernels with coalesced NHWC accesses; the NCHW<->NHWC boundary conversion of the
 // reference's external layout (API.py:80-88) is folded into them so no separate transpose pass exists.
+#include <algorithm>
+
 #include "ian_internal.h"
 
 namespace ian {
@@ -754,7 +756,9 @@ hipError_t launch_mdc_head_wgrad(const MdcHeadWgradArgs& a, int nblocks, int Cin
     }                                                                                                             \
     hipLaunchKernelGGL(k, dim3(nblocks), dim3(512), lds, s, a);                                                   \
   }
-  if (Cin == 128 && Cout <= 2) MW_LAUNCH(128, 2)
+  if (Cin == 4 && Cout <= 2) MW_LAUNCH(4, 2)
+  else if (Cin == 4) MW_LAUNCH(4, 4)
+  else if (Cin == 128 && Cout <= 2) MW_LAUNCH(128, 2)
   else if (Cin == 128) MW_LAUNCH(128, 4)
   else if (Cin == 64 && Cout <= 2) MW_LAUNCH(64, 2)
   else if (Cin == 64) MW_LAUNCH(64, 4)
@@ -763,6 +767,64 @@ hipError_t launch_mdc_head_wgrad(const MdcHeadWgradArgs& a, int nblocks, int Cin
   const int per = a.ntaps * cpad * Cin;
   hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((per + 255) / 256), dim3(256), 0, s, a.partial, nblocks, a.ntaps, cpad, Cin,
                      dS, f_rows, f_cols);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// "thin" MDCL: at most 4 real input channels AND at most 4 filters (IAN.py:187-206: G_b reads the 2-channel R map,
+// B_b the 4-channel [R,G] map; forward and backward-data).  (The kernel also instantiates for 64-256 output
+// channels, but that form lost 10x to the padded MFMA tile and is not dispatched.)
+// On the MFMA path the contraction pads 2-4 channels to 32.  Here a thread owns one output channel: its
+// taps x 4 weights live in registers for the whole pixel loop, the 16-byte input pixel is read straight from
+// global/L1 (all output-channel lanes of a pixel share the address), 4 FMAs per tap, coalesced NHWC stores.
+//   y[p][co] = act((sum_t sum_ci x[p+d_t][ci] * w[t][co][ci] + res[p][co]) * scale[co] + shift[co])
+// ------------------------------------------------------------------------------------------------
+constexpr int MT_MAXT = 36;
+template <int CO_T>  // output-channel lanes per pixel: 4 (Cout <= 4) or Cout (64 / 128 / 256)
+__global__ __launch_bounds__(512) void mdc_thin_kernel(MdcThinArgs a) {
+  constexpr int PG = 512 / CO_T;  // pixels in flight per block
+  const int co = threadIdx.x % CO_T, grp = threadIdx.x / CO_T;
+  const bool co_ok = co < a.Cout;
+  float4 wr[MT_MAXT];
+#pragma unroll
+  for (int t = 0; t < MT_MAXT; ++t)
+    wr[t] = (t < a.ntaps && co_ok) ? *reinterpret_cast<const float4*>(a.w + ((size_t)t * a.CoutPad + co) * a.CinPad)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float sc = (a.scale && co_ok) ? a.scale[co] : 1.f, sh = (a.shift && co_ok) ? a.shift[co] : 0.f;
+  const long long npix = (long long)a.n * a.H * a.W;
+  for (long long p = (long long)blockIdx.x * PG + grp; p < npix; p += (long long)gridDim.x * PG) {
+    const int px = (int)(p % a.W), py = (int)((p / a.W) % a.H);
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < MT_MAXT; ++t) {
+      if (t < a.ntaps) {
+        const int iy = py + a.dy[t], ix = px + a.dx[t];
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+          const float4 xv = *reinterpret_cast<const float4*>(a.x + (p + (long long)a.dy[t] * a.W + a.dx[t]) * a.xs);
+          acc = fmaf(xv.x, wr[t].x, acc);
+          acc = fmaf(xv.y, wr[t].y, acc);
+          acc = fmaf(xv.z, wr[t].z, acc);
+          acc = fmaf(xv.w, wr[t].w, acc);
+        }
+      }
+    }
+    if (co_ok) {
+      const size_t off = (size_t)p * a.ys + co;
+      if (a.res) acc += a.res[off];
+      a.y[off] = m_act(acc * sc + sh, a.act);
+    }
+  }
+}
+
+hipError_t launch_mdc_thin(const MdcThinArgs& a, hipStream_t s) {
+  if (a.ntaps > MT_MAXT || a.Cout < 1) return hipErrorInvalidValue;
+  const long long npix = (long long)a.n * a.H * a.W;
+  auto blocks = [&](int pg) { return (int)std::min<long long>((npix + pg - 1) / pg, 256 * 8); };
+  if (a.Cout <= 4) hipLaunchKernelGGL(mdc_thin_kernel<4>, dim3(blocks(128)), dim3(512), 0, s, a);
+  else if (a.Cout == 64) hipLaunchKernelGGL(mdc_thin_kernel<64>, dim3(blocks(8)), dim3(512), 0, s, a);
+  else if (a.Cout == 128) hipLaunchKernelGGL(mdc_thin_kernel<128>, dim3(blocks(4)), dim3(512), 0, s, a);
+  else if (a.Cout == 256) hipLaunchKernelGGL(mdc_thin_kernel<256>, dim3(blocks(2)), dim3(512), 0, s, a);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
