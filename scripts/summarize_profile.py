@@ -25,7 +25,7 @@ import os
 import sys
 
 STEPS = 20
-FIRST_KERNEL = "conv1_nchw_kernel"
+FIRST_KERNEL = "conv1_"   # conv1_mfma_kernel or conv1_nchw_kernel: first launch of a reconstruction step
 
 
 def short(name):
