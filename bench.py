@@ -126,11 +126,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local)
+    # IAN_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised on a single-GPU box (ranks share cuda:0)
+    backend = os.environ.get("IAN_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local % torch.cuda.device_count() if backend != "nccl" else local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     from neural_photo_editor_amd import IAN
     from oracle import ian_oracle as O  # synthetic parameter / image generators + cpu_baseline only
@@ -167,7 +169,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

@@ -84,7 +84,10 @@ class Comm:
         if self.world == 1:
             out.copy_(local)
             return
-        self.dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+        if self.dist.get_backend(self.group) == "nccl":       # RCCL: one fused all-gather
+            self.dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+        else:                                                   # gloo (tests): list form, row blocks are views of `out`
+            self.dist.all_gather(list(out.chunk(self.world, dim=0)), local.contiguous(), group=self.group)
 
 
 # ======================================================================================================
