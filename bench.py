@@ -33,8 +33,8 @@ FLOP_PER_RECON = {"IAN_simple": 2.592e9, "IAN": 8.463e9}
 
 def cpu_baseline(arch, P, batch, budget_s=20.0):
     import torch
-    from oracle.torch_twin import TorchTwin
-    from oracle import ian_oracle as O
+    from oracle.torch_twin import TorchTwin      # the ONLY use of oracle/ in this file: the timed CPU baseline
+    from neural_photo_editor_amd import synthetic as O
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     tw = TorchTwin(arch, P)
@@ -81,9 +81,8 @@ def train_step_bench(batch, rank, world, iters=3):
     """ms per update_gen / update_discrim (train_IAN.py:309-329) of the full IAN at `batch` images per GPU."""
     import torch
     from neural_photo_editor_amd.trainer import Trainer, Comm
-    from oracle import ian_oracle as O           # synthetic parameter generator only
-    from oracle.train_twin import make_train_params
-    P = make_train_params(O.make_params("IAN", 1))
+    from neural_photo_editor_amd import synthetic as O
+    P = O.make_train_params(O.make_params("IAN", 1))
     tr = Trainer(os.path.join(ROOT, "neural_photo_editor_amd", "configs", "IAN.py"), P, batch=batch, comm=Comm(), exact=True)
     rs = np.random.RandomState(50 + rank)
     X = torch.from_numpy(O.make_images(batch, seed=200 + rank)).cuda()
@@ -135,7 +134,7 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world)
 
     from neural_photo_editor_amd import IAN
-    from oracle import ian_oracle as O  # synthetic parameter / image generators + cpu_baseline only
+    from neural_photo_editor_amd import synthetic as O   # seeded synthetic parameters / images (no trained weights exist)
 
     arch = args.arch
     B = args.batch or (64 if arch == "IAN_simple" else 256)

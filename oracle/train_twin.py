@@ -57,21 +57,7 @@ def decoder_param_names():
     return names
 
 
-def train_param_shapes():
-    """Shapes of the training-only parameters (discriminator head), IAN.py:209-216, layers.py:487-495."""
-    return {"minibatch_discrim.theta": (1024, 500, 5), "minibatch_discrim.log_weight_scale": (500, 5),
-            "minibatch_discrim.b": (500,), "discrimi.W": (1524, 3)}
-
-
-def make_train_params(P, seed=3):
-    """Adds seeded discriminator-head parameters to an inference parameter dict (oracle.make_params('IAN'))."""
-    rs = np.random.RandomState(seed)
-    Q = dict(P)
-    Q["minibatch_discrim.theta"] = rs.normal(0, 0.05, (1024, 500, 5)).astype(np.float32)      # layers.py:487
-    Q["minibatch_discrim.log_weight_scale"] = rs.normal(0, 0.1, (500, 5)).astype(np.float32)  # Constant(0) perturbed
-    Q["minibatch_discrim.b"] = (-1.0 + rs.normal(0, 0.1, (500,))).astype(np.float32)          # Constant(-1) perturbed
-    Q["discrimi.W"] = rs.normal(0, 0.02, (1524, 3)).astype(np.float32)
-    return Q
+from neural_photo_editor_amd.synthetic import make_train_params, train_param_shapes  # noqa: E402,F401
 
 
 def ortho_res(params):
