@@ -146,3 +146,34 @@ def test_brush_gradients_vs_finite_differences():
         assert abs(fdl - gl[0, k]) < 1e-6 + 1e-4 * abs(gl[0, k])
     gold = np.load(os.path.join(GOLD, "IAN_simple_seed1.npz"))
     assert rel(g, gold["grad_rgb"]) < 1e-5 and rel(gl, gold["grad_light"]) < 1e-5
+
+
+def test_c_restatement_agrees_with_numpy_oracle():
+    """oracle/ian_primitives.c (plain C, float64 accumulation): third independent statement of the conv / transposed
+    conv / MDCL index conventions; must agree with the numpy restatement (and through it with the torch twin)."""
+    import ctypes
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle")], check=True)
+    lib = ctypes.CDLL(os.path.join(root, "oracle", "_ref", "libian_primitives.so"))
+    fp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rs = np.random.RandomState(0)
+    N, Cin, H, Cout = 2, 5, 8, 7
+    x = rs.randn(N, Cin, H, H).astype(np.float32)
+    W = rs.randn(Cout, Cin, 5, 5).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32)
+    y = np.zeros((N, Cout, H // 2, H // 2), np.float32)
+    lib.ref_conv5s2(fp(x), fp(W), fp(b), fp(y), N, Cin, H, H, Cout)
+    assert np.abs(y - O.conv5s2(x, W, b)).max() < 1e-4
+    Wd = rs.randn(Cin, Cout, 5, 5).astype(np.float32)
+    for flip in (1, 0):
+        yd = np.zeros((N, Cout, 2 * H, 2 * H), np.float32)
+        lib.ref_deconv5s2(fp(x), fp(Wd), fp(yd), N, Cin, H, H, Cout, flip)
+        assert np.abs(yd - O.deconv5s2(x, Wd, None, bool(flip))).max() < 1e-4
+    Wm = rs.randn(Cout, Cin, 3, 3).astype(np.float32)
+    scales = np.array([0, 2, 3], np.int32)
+    coeffs = rs.uniform(0.5, 1.5, (4, Cout)).astype(np.float32)
+    P = {"mW": Wm, "m_coeff_base": coeffs[0], "m_coeff_1x1": coeffs[1], "m_coeff_2": coeffs[2], "m_coeff_3": coeffs[3]}
+    ym = np.zeros((N, Cout, H, H), np.float32)
+    lib.ref_mdcl(fp(x), fp(Wm), fp(coeffs), fp(scales), 3, fp(ym), N, Cin, H, H, Cout)
+    assert np.abs(ym - O.mdcl(x, P, "m", [0, 2, 3])).max() < 1e-4
