@@ -140,6 +140,7 @@ struct ian_handle {
   // its forward pass.  Any other use of the decoder slots invalidates it.
   long long run_serial = 0;  // incremented per executed segment (fused head bookkeeping)
   std::vector<float> dec_cache_z;
+  std::vector<float> rgb_cache;  // host copy of the brush image last uploaded to d_rgb
   bool dec_cache_valid = false;
   // profiling
   bool prof = false;
@@ -1296,7 +1297,12 @@ int grad_common(ian_handle* h, int mode, int c1, int r1, int c2, int r2, const f
     if (is_device_ptr(rgb)) d_rgb = rgb;
     else {
       if (!h->d_rgb) HIPCHK(h, hipMalloc((void**)&h->d_rgb, cnt * sizeof(float)));
-      HIPCHK(h, hipMemcpyAsync(h->d_rgb, rgb, cnt * sizeof(float), hipMemcpyHostToDevice, st));
+      // the brush colour image rarely changes between motion events (NPE.py:205 passes the same myRGB): re-upload
+      // only when the host bytes differ from the last upload
+      if (h->rgb_cache.size() != cnt || memcmp(h->rgb_cache.data(), rgb, cnt * sizeof(float)) != 0) {
+        HIPCHK(h, hipMemcpyAsync(h->d_rgb, rgb, cnt * sizeof(float), hipMemcpyHostToDevice, st));
+        h->rgb_cache.assign(rgb, rgb + cnt);
+      }
       d_rgb = h->d_rgb;
     }
   }

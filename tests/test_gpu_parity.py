@@ -182,6 +182,15 @@ def test_decoder_forward_cache_is_transparent():
     m.sample_at(z1)
     m.reconstruct(O.make_images(1, seed=3))                                  # clobbers the decoder activations
     assert np.array_equal(m.imgradRGB(26, 26, 30, 30, rgb, z1), cold1)
+    rgb2 = rgb.copy()
+    rgb2[0, :, 26:30, 26:30] = 0.25                                          # another colour: the upload cache must notice
+    os.environ["IAN_NO_DEC_CACHE"] = "1"
+    try:
+        a = m.imgradRGB(26, 26, 30, 30, rgb2, z1)
+    finally:
+        del os.environ["IAN_NO_DEC_CACHE"]
+    assert not np.array_equal(a, cold1)
+    assert np.array_equal(m.imgradRGB(26, 26, 30, 30, rgb, z1), cold1) and np.array_equal(m.imgradRGB(26, 26, 30, 30, rgb2, z1), a)
     m.sample_at(np.concatenate([z1, z2]))                                    # batch 2: not cacheable
     assert np.array_equal(m.imgrad(26, 26, 30, 30, z1), m.imgrad(26, 26, 30, 30, z1.copy()))
 
