@@ -243,3 +243,19 @@ def test_training_loop_end_to_end(setup, tmp_path):
         assert "dec_conv1.W" in f.files and "bnorm2.inv_std" in f.files and "metadata" in f.files
     _, meta = checkpoints.load_weights(wf, [])
     assert meta["epoch"] == 0 and meta["itr"] == 4
+
+
+def test_train_cli_runs_an_epoch(tmp_path):
+    """python -m neural_photo_editor_amd.train_cli <config> --data ... : the train_IAN.py command line on the HIP path."""
+    from neural_photo_editor_amd import train_cli, train_loop as TL
+    src = open(CFG).read().replace("batch_size=16", "batch_size=4").replace("batches_per_chunk=64", "batches_per_chunk=2") \
+        .replace("max_epochs=80", "max_epochs=1")
+    assert "batch_size=4" in src and "batches_per_chunk=2" in src
+    cfg_path = str(tmp_path / "IAN.py")
+    open(cfg_path, "w").write(src)
+    np.save(str(tmp_path / "imgs.npy"), np.uint8((O.make_images(16, seed=5) + 1) * 127.5))
+    train_cli.main([cfg_path, "--data", str(tmp_path / "imgs.npy")])
+    recs = TL.read_records(str(tmp_path / "IANMETRICS.jsonl"))
+    assert len(recs) == 2 and recs[-1]["itr"] == 4 and os.path.exists(str(tmp_path / "IAN.npz"))
+    train_cli.main([cfg_path, "--data", str(tmp_path / "imgs.npy"), "--resume", "--epochs", "2"])     # resumes at epoch 1
+    assert len(TL.read_records(str(tmp_path / "IANMETRICS.jsonl"))) == 4

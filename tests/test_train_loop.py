@@ -108,3 +108,21 @@ def test_npe_host_steps():
     assert np.allclose(mask, np.abs(delta).mean(0), atol=1e-5)                   # constant field: the Gaussian leaves it unchanged
     want = np.uint8(npe_ops.from_tanh(npe_ops.to_tanh(recon) + mask * delta))
     assert np.abs(im.astype(int) - want.astype(int)).max() <= 1
+
+
+def test_train_cli_arguments_and_data_loading(tmp_path):
+    from neural_photo_editor_amd import train_cli
+    a = train_cli.parse_args(["cfg/IAN.py", "--resume", "--epochs", "2", "--batch", "8"])
+    assert a.config_path == "cfg/IAN.py" and a.resume and a.epochs == 2 and a.batch == 8 and not a.local_statistics
+    assert train_cli.load_images(None, 6).shape == (6, 3, 64, 64)
+    imgs = np.random.RandomState(0).randint(0, 256, (5, 3, 64, 64)).astype(np.uint8)
+    np.save(str(tmp_path / "d.npy"), imgs)
+    np.savez(str(tmp_path / "d.npz"), images=imgs)
+    assert np.array_equal(train_cli.load_images(str(tmp_path / "d.npy")), imgs)
+    assert np.array_equal(train_cli.load_images(str(tmp_path / "d.npz")), imgs)
+    np.save(str(tmp_path / "bad.npy"), imgs.astype(np.float32))
+    try:
+        train_cli.load_images(str(tmp_path / "bad.npy"))
+        assert False
+    except ValueError:
+        pass
