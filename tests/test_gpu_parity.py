@@ -255,3 +255,16 @@ def test_every_decoder_gradient_buffer(arch):
     full = m.imgrad(0, 0, 64, 64, z)
     parts = [m.imgrad(c1, r1, c1 + 32, r1 + 32, z) for c1 in (0, 32) for r1 in (0, 32)]
     assert rel(sum(parts) / 4.0, full) < 1e-4
+
+
+def test_sample_cli_writes_the_grid(tmp_path):
+    """python sample_IAN.py <config> equivalent: 27 samples + 3 x [endpoint, 7 interpolants, endpoint] -> 6x9 grid."""
+    from neural_photo_editor_amd import sample_cli
+    cfg = str(tmp_path / "IAN.py")
+    open(cfg, "w").write(open(os.path.join(CFG, "IAN.py")).read())
+    with pytest.warns(UserWarning):
+        out = sample_cli.main([cfg, "--out", str(tmp_path / "g.ppm")])
+    data = open(out, "rb").read()
+    assert data.startswith(b"P6\n576 384\n255\n") and len(data) == len(b"P6\n576 384\n255\n") + 384 * 576 * 3
+    imgs = np.load(str(tmp_path / "g.npy"))
+    assert imgs.shape == (54, 3, 64, 64) and imgs.dtype == np.uint8 and imgs.std() > 0
