@@ -44,6 +44,19 @@ def _fresh(dig):
     return False
 
 
+def have_hipcc():
+    try:
+        _hipcc()
+        return True
+    except RuntimeError:
+        return False
+
+
+def is_fresh():
+    """The in-tree libian.so was built from exactly the sources now under csrc/."""
+    return _fresh(_digest())
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link libian.so. Returns the library path.
     Safe to call from several processes at once (one rank per GPU): the build is serialised by a file lock and the
@@ -80,10 +93,12 @@ def _build_locked(dig, verbose):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    tmp = LIB + ".%d.tmp" % os.getpid()      # never link over a library other ranks may have mapped
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stdout.decode(errors="replace"))
+    os.replace(tmp, LIB)
     with open(STAMP, "w") as fh:
         fh.write(dig)
     return LIB

@@ -58,11 +58,13 @@ def load_library():
     if _lib is not None:
         return _lib
     path = _build.LIB
-    try:
-        path = _build.build()
-    except Exception as exc:  # no hipcc on this machine: use the shipped .so if there is one
-        if not os.path.exists(path):
-            raise RuntimeError("libian.so is missing and cannot be built: %s" % exc)
+    if _build.have_hipcc():
+        path = _build.build()      # a compile / link error propagates: never run stale kernels behind a failed build
+    elif not os.path.exists(path):
+        raise RuntimeError("libian.so is missing and hipcc is not available to build it")
+    elif not _build.is_fresh():
+        raise RuntimeError("libian.so does not match the sources under csrc/ (digest stamp differs) and hipcc is not "
+                           "available to rebuild it")
     lib = C.CDLL(path)
     vp, i32, fp = C.c_void_p, C.c_int32, C.c_void_p
     lib.ian_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]

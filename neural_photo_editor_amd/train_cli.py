@@ -22,7 +22,7 @@ def parse_args(argv=None):
     ap.add_argument("--resume", action="store_true", help="continue from <config>.npz (train_IAN.py:423-430)")
     ap.add_argument("--data", default=None, help=".npy/.npz uint8 images (N,3,64,64)")
     ap.add_argument("--epochs", type=int, default=None, help="override cfg['max_epochs']")
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU minibatch (default cfg['batch_size'])")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU minibatch (default cfg['batch_size'] / world: the reference's batch is the global one)")
     ap.add_argument("--local-statistics", action="store_true",
                     help="data parallel without SyncBN / MinibatchLayer all-gather (faster, not the reference's arithmetic)")
     return ap.parse_args(argv)
@@ -41,12 +41,18 @@ def load_images(path, n_synth=256):
     return arr
 
 
+def initial_params(specs, seed=0):
+    """name -> float32 array drawn from each parameter's recorded lasagne initialiser (config_loader.Init.sample)."""
+    rs = np.random.RandomState(seed)
+    return {p.name: p.init.sample(p.shape, rs) for p in specs}
+
+
 def main(argv=None):
     args = parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s| %(message)s")
     import torch
     import torch.distributed as dist
-    from . import checkpoints, config_loader, lowering, synthetic, train_loop
+    from . import checkpoints, config_loader, lowering, train_loop
     from .trainer import Comm, Trainer
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
@@ -57,17 +63,20 @@ def main(argv=None):
     mod = config_loader.load_config(args.config_path)
     cfg = dict(mod.cfg)
     weights_fname = str(args.config_path)[:-3] + ".npz"                      # train_IAN.py:384
-    params, meta = synthetic.make_train_params(synthetic.make_params("IAN", seed=1)), {}
+    model = config_loader.build_model(mod)
+    specs = lowering.all_param_specs(model)                                  # l_out + l_Z + l_discrim + batch-norm statistics
+    # A fresh run starts from the config's own initialisers (IAN.py: Normal(0.02) filters, Orthogonal('relu') MADE,
+    # gamma 1 / beta 0, mean 0 / inv_std 1, theta ~ N(0,0.05), b = -1: what lasagne would draw for train_IAN.py:381-392),
+    # seeded per config so that every rank of a data-parallel job draws the same values.
+    params, meta = initial_params(specs, cfg.get("seed", 0)), {}
     if args.resume and os.path.isfile(weights_fname):
-        specs = lowering.all_param_specs(config_loader.build_model(mod))
         loaded, meta = checkpoints.load_weights(weights_fname, specs)
         params.update(loaded)
-        with np.load(weights_fname, allow_pickle=True) as f:                 # discriminator head is not part of the inference specs
-            for k in f.files:
-                if k.startswith("minibatch_discrim.") or k == "discrimi.W":
-                    params[k] = np.asarray(f[k], np.float32)
-    batch = args.batch or cfg["batch_size"]
-    cfg["batch_size"] = batch * world                                        # the reference's batch is the GLOBAL minibatch
+    # the reference's batch_size is the GLOBAL minibatch (one Theano function call): each rank takes 1/world of it
+    if args.batch is None and cfg["batch_size"] % world:
+        raise SystemExit("cfg['batch_size']=%d is not divisible by the %d ranks; pass --batch" % (cfg["batch_size"], world))
+    batch = args.batch or cfg["batch_size"] // world
+    cfg["batch_size"] = batch * world
     trainer = Trainer(args.config_path, params, batch=batch, comm=Comm(), exact=not args.local_statistics)
     images = load_images(args.data)
     rank = int(os.environ.get("RANK", "0"))

@@ -142,7 +142,12 @@ def train(cfg, trainer, dataset, weights_fname, metrics_fname=None, resume=False
     being resumed (epoch, learning_rate) -- the weights themselves are loaded by whoever built the trainer."""
     to_device = to_device or (lambda a: a)
     metrics_fname = metrics_fname or str(weights_fname)[:-4] + "METRICS.jsonl"
-    mlog = MetricsLogger(metrics_fname, reinitialize=not resume)
+    # data parallel: every rank runs this loop on its shard; the files (metrics log, sample grid, checkpoint) belong to
+    # rank 0 alone, the other ranks wait at a barrier so nobody races ahead of a half-written checkpoint
+    comm = getattr(trainer, "comm", None)
+    rank = getattr(comm, "rank", 0)
+    barrier = getattr(comm, "barrier", None) or (lambda: None)
+    mlog = MetricsLogger(metrics_fname, reinitialize=not resume) if rank == 0 else None
     itr = 0
     min_epoch = 0
     if resume and load_metadata:
@@ -161,10 +166,13 @@ def train(cfg, trainer, dataset, weights_fname, metrics_fname=None, resume=False
         for x_chunk in loader:
             metrics, itr = train_chunk(trainer, cfg, x_chunk, itr, rng, to_device)
             logging.info("%4d %6d  %s", epoch, itr, "  ".join("%s %.4f" % kv for kv in metrics.items()))
-            mlog.log(epoch=epoch, itr=itr, metrics=metrics)
+            if mlog:
+                mlog.log(epoch=epoch, itr=itr, metrics=metrics)
         if not (epoch % cfg["checkpoint_every_nth"]):
-            if checkpoint_fn:
-                checkpoint_fn(epoch)
-            trainer.save_weights(weights_fname, {"epoch": epoch, "itr": itr, "ts": time.time(), "learning_rate": np.float32(trainer.lr)})
+            if rank == 0:
+                if checkpoint_fn:
+                    checkpoint_fn(epoch)
+                trainer.save_weights(weights_fname, {"epoch": epoch, "itr": itr, "ts": time.time(), "learning_rate": float(trainer.lr)})
+            barrier()
     logging.info("training done")
     return itr

@@ -79,6 +79,10 @@ class Comm:
                 works.append(w)
         return works
 
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier(group=self.group)
+
     def all_gather_rows(self, local, out):
         """out[(rank*n):(rank+1)*n] = local over all ranks (row blocks of equal size)."""
         if self.world == 1:

@@ -133,6 +133,56 @@ def test_checkpoint_roundtrip_and_mismatch_policy(tmp_path):
     assert np.array_equal(got["enc_conv1.W"], arrays["enc_conv1.W"])
 
 
+def test_metadata_is_written_the_way_the_reference_reads_it(tmp_path):
+    """GANcheckpoints.py:54 does ``pickle.loads(str(param_dict['metadata']))`` under Python 2: the entry must be a 0-d
+    '|S' array holding a protocol-0 (ASCII) pickle of plain Python values -- no numpy._core references, which
+    Python-2 numpy could not import."""
+    import pickle
+    import pickletools
+    f = tmp_path / "w.npz"
+    checkpoints.save_weights(f, {"enc_conv1.b": np.zeros(128, np.float32)},
+                             metadata={"epoch": 3, "itr": 1200, "ts": 1474000000.25, "learning_rate": np.float32(2e-4), "note": "x"})
+    with np.load(str(f), allow_pickle=False) as a:       # loads without pickle support: no object arrays inside
+        m = a["metadata"]
+        assert m.shape == () and m.dtype.kind == "S"
+        raw = m.item()
+    assert raw.startswith(b"(dp0\nS'epoch'\np1\nI3\ns") and raw.endswith(b"s.")   # cPickle protocol-0 text
+    assert b"numpy" not in raw and max(raw) < 128
+    ops = [op.name for op, _, _ in pickletools.genops(raw)]
+    assert "GLOBAL" not in ops and "REDUCE" not in ops
+    meta = pickle.loads(raw)                             # the reference's decode, in today's Python
+    assert meta == {"epoch": 3, "itr": 1200, "ts": 1474000000.25, "learning_rate": float(np.float32(2e-4)), "note": "x"}
+    assert type(meta["learning_rate"]) is float
+    with pytest.raises(TypeError):
+        checkpoints.save_weights(f, {}, metadata={"bad": np.zeros(3)})
+
+
+def test_python2_style_checkpoint_fixture_loads():
+    """tests/golden/py2_style_checkpoint.npz (made by make_py2_checkpoint.py) is laid out as GANcheckpoints.save_weights
+    writes under Python 2: '|S' metadata = cPickle protocol-0 text incl. the numpy.core.multiarray.scalar reduce of
+    np.float32(learning_rate) (train_IAN.py:571).  Loaded with allow_pickle=False + the restricted unpickler."""
+    _, low = lowered(os.path.join(CFG, "IAN_simple.py"))
+    fx = os.path.join(ROOT, "tests", "golden", "py2_style_checkpoint.npz")
+    specs = lowering.all_param_specs(cl.build_model(cl.load_config(os.path.join(CFG, "IAN_simple.py"))))
+    with pytest.warns(UserWarning, match="shape mismatch:enc_conv1.W"):
+        got, meta = checkpoints.load_weights(fx, specs, extra_prefixes=("discrimi.", "minibatch_discrim."))
+    assert meta["epoch"] == 3 and meta["itr"] == 1200 and meta["ts"] == 1474000000.25
+    assert isinstance(meta["learning_rate"], np.float32) and meta["learning_rate"] == np.float32(2e-4)
+    assert {"mu_bnorm.gamma", "mu_bnorm.mean", "mu_bnorm.inv_std", "enc_conv1.b", "dec_out.W", "discrimi.W"} <= set(got)
+    assert "enc_conv1.W" not in got and got["dec_out.W"].shape == (128, 3, 5, 5) and got["dec_out.W"].dtype == np.float32
+    rs = np.random.RandomState(7)
+    assert np.array_equal(got["mu_bnorm.gamma"], rs.uniform(0.5, 1.5, 100).astype(np.float32))
+
+
+def test_metadata_unpickler_refuses_code():
+    import pickle
+    evil = b"cos\nsystem\n(S'echo pwned'\ntR."
+    with pytest.raises(pickle.UnpicklingError):
+        checkpoints.loads_metadata(evil)
+    with pytest.raises(pickle.UnpicklingError):
+        checkpoints.loads_metadata(np.array(evil))
+
+
 # ---- C ABI ---------------------------------------------------------------------------------------------------
 def test_library_builds_loads_and_exports_header_symbols():
     lib = L.load_library()
