@@ -58,10 +58,18 @@ void ian_layer_destroy(ian_layer* l);
 const char* ian_k_last_error(void);
 /* per-channel sums over NHWC rows, two-stage: workspace >= nchunks*2*C floats, sums = [2][C].
    mode 0: (sum x, sum x^2) of x.   mode 1: g = x*act'(a): (sum g, sum g*xhat), xhat=(y-mean)*inv_std.
-   mode 2: g = x*act'(a): (sum g, -).                                   batch_norm / bias gradients (App. B.3) */
+   mode 2: g = x*act'(a): (sum g, -).                                   batch_norm / bias gradients (App. B.3)
+   The rows are cut into nchunks equal chunks (rows % nchunks == 0 for the guarantee below), each summed in a fixed
+   order, and the chunk partials meet in a pairwise tree over the chunk index (ian_k_tree_sum).  With power-of-two
+   chunk counts the result over a whole minibatch equals, bit for bit, the tree over ranks of per-rank results
+   computed with the same chunk size: the data-parallel batch statistics are those of the single-process step. */
 int ian_k_colstats(int32_t mode, const float* x, const float* a, const float* y, const float* mean, const float* inv_std,
                    int64_t rows, int32_t C, int32_t stride, int32_t act, float* workspace, int32_t nchunks, float* sums,
                    void* stream);
+/* out[i] = pairwise tree (T(lo,hi) = T(lo,lo+m) + T(lo+m,hi), m = largest power of two below hi-lo) over k < count
+   of partial[k*width + i]: the second stage of ian_k_colstats, and the rank-ordered combine of all-gathered
+   per-rank sums (SyncBN) */
+int ian_k_tree_sum(const float* partial, int32_t count, int32_t width, float* out, void* stream);
 /* batch statistics -> mean, inv_std = 1/sqrt(var+eps), scale = gamma*inv_std, shift = beta - mean*scale */
 int ian_k_bn_make_affine(const float* sums, float count, float eps, const float* gamma, const float* beta, int32_t C,
                          float* mean, float* inv_std, float* scale, float* shift, void* stream);

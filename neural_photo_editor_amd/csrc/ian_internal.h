@@ -235,6 +235,8 @@ struct ColStatsArgs {
   int C, stride, mode, act;
 };
 hipError_t launch_colstats(const ColStatsArgs& a, int nchunks, float* sums, hipStream_t s);
+// out[i] = pairwise tree over k < count of partial[k*width + i] (fixed order: see kernels_train.hip)
+hipError_t launch_tree_sum(const float* partial, int count, int width, float* out, hipStream_t s);
 hipError_t launch_bn_make_affine(const float* sums, float count, float eps, const float* gamma, const float* beta,
                                  int C, float* mean, float* inv_std, float* scale, float* shift, hipStream_t s);
 struct BnBwdArgs {

@@ -40,6 +40,11 @@ int ian_k_colstats(int32_t mode, const float* x, const float* a, const float* y,
   return chk(launch_colstats(s, nchunks, sums, ST), "ian_k_colstats");
 }
 
+int ian_k_tree_sum(const float* partial, int32_t count, int32_t width, float* out, void* stream) {
+  if (!partial || !out || count <= 0 || width <= 0 || count >= 65536) return bad("ian_k_tree_sum");
+  return chk(launch_tree_sum(partial, count, width, out, ST), "ian_k_tree_sum");
+}
+
 int ian_k_bn_make_affine(const float* sums, float count, float eps, const float* gamma, const float* beta, int32_t C,
                          float* mean, float* inv_std, float* scale, float* shift, void* stream) {
   if (!sums || !gamma || !beta || !mean || !inv_std || !scale || !shift || C <= 0 || count <= 0) return bad("ian_k_bn_make_affine");

@@ -39,11 +39,19 @@ static inline int grid_for(long long total, int cap = 8192) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-channel column statistics over NHWC rows.  partial[chunk][2][C]; then colstats_finalize -> sums[2][C]
+// per-channel column statistics over NHWC rows.  partial[chunk][2][C]; then tree_sum -> sums[2][C]
 //   mode 0: s1 = sum x,  s2 = sum x^2                          (batch-norm forward statistics)
 //   mode 1: g = dA*act'(a): s1 = sum g, s2 = sum g*xhat, xhat = (y-mean)*inv_std   (batch-norm backward: dbeta, dgamma)
 //   mode 2: g = dA*act'(a): s1 = sum g                        (bias gradient)
-// block = 64 channel quads x 4 row lanes; grid = (row chunks, ceil(C/256))
+// block = 64 channel quads x 4 row lanes; grid = (row chunks, ceil(C/256)).
+//
+// Summation order is a function of the ROW INDEX only, not of how many rows there are: the caller cuts the rows
+// into equal chunks whose size depends on the per-image extent alone (trainer.py: one image or a fixed fraction
+// of one), a chunk is summed by 4 row lanes in a fixed order, and the chunk partials are combined by tree_sum,
+// a pairwise (binary-counter) tree over the chunk index.  For power-of-two chunk counts
+//     tree(chunks of the whole minibatch) == tree(rank 0's chunks) + tree(rank 1's chunks)   bit for bit,
+// so the data-parallel step (per-rank tree, all-gather, tree over ranks in rank order) computes the SAME float32
+// batch statistics as the single-process step on the whole minibatch (SyncBN).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void colstats_kernel(ColStatsArgs a) {
   __shared__ float4 red[2][256];
@@ -82,34 +90,78 @@ __global__ __launch_bounds__(256) void colstats_kernel(ColStatsArgs a) {
   red[1][threadIdx.x] = s2;
   __syncthreads();
   if (rl == 0 && c < a.C) {
-#pragma unroll
-    for (int k = 1; k < 4; ++k) {
-      const float4 u = red[0][q + 64 * k], v = red[1][q + 64 * k];
-      s1.x += u.x; s1.y += u.y; s1.z += u.z; s1.w += u.w;
-      s2.x += v.x; s2.y += v.y; s2.z += v.z; s2.w += v.w;
-    }
+    // (lane0 + lane1) + (lane2 + lane3): fixed, and independent of the number of chunks
+    const float4 u1 = red[0][q + 64], u2 = red[0][q + 128], u3 = red[0][q + 192];
+    const float4 v1 = red[1][q + 64], v2 = red[1][q + 128], v3 = red[1][q + 192];
+    s1.x = (s1.x + u1.x) + (u2.x + u3.x); s1.y = (s1.y + u1.y) + (u2.y + u3.y);
+    s1.z = (s1.z + u1.z) + (u2.z + u3.z); s1.w = (s1.w + u1.w) + (u2.w + u3.w);
+    s2.x = (s2.x + v1.x) + (v2.x + v3.x); s2.y = (s2.y + v1.y) + (v2.y + v3.y);
+    s2.z = (s2.z + v1.z) + (v2.z + v3.z); s2.w = (s2.w + v1.w) + (v2.w + v3.w);
     float* p = a.partial + (size_t)blockIdx.x * 2 * a.C;
     *reinterpret_cast<float4*>(p + c) = s1;
     *reinterpret_cast<float4*>(p + a.C + c) = s2;
   }
 }
-__global__ __launch_bounds__(256) void colstats_finalize_kernel(const float* __restrict__ partial, int nchunks, int C,
-                                                                float* __restrict__ sums) {
+
+// Pairwise tree over `count` values p[0], p[stride], ...: T(lo,hi) = T(lo,lo+m) + T(lo+m,hi) with m the largest power
+// of two below hi-lo -- evaluated left to right with a binary counter of partial sums (no recursion, registers only).
+constexpr int TS_LEVELS = 16;
+__device__ __forceinline__ float tree_sum_seq(const float* __restrict__ p, size_t stride, int count) {
+  float acc[TS_LEVELS];
+#pragma unroll
+  for (int l = 0; l < TS_LEVELS; ++l) acc[l] = 0.f;
+  for (int k = 0; k < count; ++k) {
+    float v = p[(size_t)k * stride];
+    bool placed = false;
+#pragma unroll
+    for (int l = 0; l < TS_LEVELS; ++l) {
+      if (!placed) {
+        if ((k >> l) & 1) v = acc[l] + v;   // level l holds the left sibling: combine and carry
+        else { acc[l] = v; placed = true; }
+      }
+    }
+  }
+  float r = 0.f;
+  bool have = false;
+#pragma unroll
+  for (int l = 0; l < TS_LEVELS; ++l)
+    if ((count >> l) & 1) {
+      r = have ? acc[l] + r : acc[l];
+      have = true;
+    }
+  return r;
+}
+// out[i] = tree over k of partial[k*width + i].  Block = 16 columns x 16 lanes; for a power-of-two count each lane
+// takes a contiguous 1/16th (its own subtree) and the lanes meet pairwise in LDS, which is the same tree.
+__global__ __launch_bounds__(256) void tree_sum_kernel(const float* __restrict__ partial, int count, int width,
+                                                       float* __restrict__ out) {
   __shared__ float red[256];
-  const int col = threadIdx.x & 63, lane = threadIdx.x >> 6;  // 64 columns x 4 chunk lanes (fixed summation order)
-  const int i = blockIdx.x * 64 + col;
+  const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + col;
+  const bool pow2 = (count & (count - 1)) == 0;
+  const int L = pow2 ? min(16, count) : 1;   // lanes in use
   float s = 0.f;
-  if (i < 2 * C)
-    for (int k = lane; k < nchunks; k += 4) s += partial[(size_t)k * 2 * C + i];
+  if (i < width && lane < L) {
+    const int per = count / L;
+    s = tree_sum_seq(partial + (size_t)lane * per * width + i, (size_t)width, per);
+  }
   red[threadIdx.x] = s;
   __syncthreads();
-  if (lane == 0 && i < 2 * C) sums[i] = (red[col] + red[col + 64]) + (red[col + 128] + red[col + 192]);
+  for (int w = 1; w < L; w <<= 1) {
+    if (lane % (2 * w) == 0 && lane + w < L) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 16 * w];
+    __syncthreads();
+  }
+  if (lane == 0 && i < width) out[i] = red[col];
+}
+hipError_t launch_tree_sum(const float* partial, int count, int width, float* out, hipStream_t s) {
+  if (count <= 0 || width <= 0 || count >= (1 << TS_LEVELS)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(tree_sum_kernel, dim3((width + 15) / 16), dim3(256), 0, s, partial, count, width, out);
+  return hipGetLastError();
 }
 hipError_t launch_colstats(const ColStatsArgs& a, int nchunks, float* sums, hipStream_t s) {
   if (a.C & 3) return hipErrorInvalidValue;
   hipLaunchKernelGGL(colstats_kernel, dim3(nchunks, (a.C + 255) / 256), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(colstats_finalize_kernel, dim3((2 * a.C + 63) / 64), dim3(256), 0, s, a.partial, nchunks, a.C, sums);
-  return hipGetLastError();
+  return launch_tree_sum(a.partial, nchunks, 2 * a.C, sums, s);
 }
 
 // batch statistics -> folded affine (App. B.3): mean, biased variance, inv_std = 1/sqrt(var+eps)

@@ -52,7 +52,7 @@ class Comm:
     """Sum-all-reduce / all-gather for the data-parallel step.  ``bucket_bytes`` sizes the gradient buckets for
     xGMI (point-to-point links: a few large messages)."""
 
-    def __init__(self, group=None, bucket_bytes=64 << 20):
+    def __init__(self, group=None, bucket_bytes=16 << 20):
         import torch.distributed as dist
         self.dist = dist
         self.active = dist.is_available() and dist.is_initialized()
@@ -78,6 +78,20 @@ class Comm:
             if async_op:
                 works.append(w)
         return works
+
+    def all_reduce_sum_ordered(self, t, k):
+        """t <- sum over ranks of t, combined in RANK ORDER by the same pairwise tree the per-rank reduction uses
+        (all-gather + ian_k_tree_sum): the result does not depend on the collective's internal algorithm, and with
+        power-of-two per-rank chunk counts it equals the single-process reduction bit for bit (SyncBN).
+        Only used for the tiny per-channel statistic vectors (<= 2 x 16384 floats)."""
+        if self.world == 1:
+            return
+        need = t.numel() * self.world
+        buf = getattr(self, "_gbuf", None)
+        if buf is None or buf.numel() < need or buf.device != t.device:
+            buf = self._gbuf = t.new_empty(need)
+        self.all_gather_rows(t.view(1, -1), buf[:need].view(self.world, -1))
+        k.tree_sum(buf, self.world, t.numel(), t)
 
     def barrier(self):
         if self.world > 1:
@@ -221,6 +235,24 @@ class BN:
         self.count = 1.0
 
 
+class _WriteLog(set):
+    """The set of parameters whose gradient has been written in this backward sweep; every insertion is also reported to
+    the trainer, which uses the sequence to launch a gradient bucket's all-reduce right after its LAST writer."""
+
+    def __init__(self, owner):
+        set.__init__(self)
+        self.owner = owner
+
+    def add(self, name):
+        set.add(self, name)
+        self.owner._wrote((name,))
+
+    def update(self, names):
+        names = tuple(names)
+        set.update(self, names)
+        self.owner._wrote(names)
+
+
 class Trainer:
     """update_gen / update_discrim of train_IAN.py on one GPU (or one rank of a data-parallel job)."""
 
@@ -244,7 +276,11 @@ class Trainer:
         self._build_params(params)
         self._build_layers(deconv_flip)
         self._alloc()
-        self.touched = set()
+        self._plans, self._works, self._fired, self._buckets = {}, [], set(), None
+        self._ev, self._evlog, self.overlap_log = 0, [], []
+        self.overlap = True                      # data parallel: all-reduce gradient buckets while backward still runs
+        self.side = torch.cuda.Stream() if self.comm.world > 1 else None
+        self.touched = _WriteLog(self)
         self.update_running = True
 
     # ---------------------------------------------------------------------------------------------
@@ -360,13 +396,26 @@ class Trainer:
     # ---------------------------------------------------------------------------------------------
     # building blocks
     # ---------------------------------------------------------------------------------------------
+    def _chunks(self, rows):
+        """Row chunks of ian_k_colstats: the chunk SIZE depends on the per-image extent only (one image, or 512 rows of
+        one), never on the batch, so a rank's partial sums are the very partial sums the single-process step forms for
+        the same images (rank-order-invariant batch statistics; include/ian_train.h)."""
+        rpi = max(1, rows // self.n)
+        return self.n * max(1, rpi // 512) if rows == self.n * rpi else min(256, rows)
+
+    def _ws(self, rows, C):
+        need = self._chunks(rows) * 2 * C
+        if self.ws_stats.numel() < need:
+            self.ws_stats = self.torch.zeros(need, dtype=self.torch.float32, device=self.dev)
+        return self.ws_stats
+
     def _bn_forward(self, bn, y, a, rows, C, stride, gamma, beta, act, count_rows, running=None):
         """batch statistics over this pass (all ranks when exact) -> a = act(bn(y)).  ``running``: name of the
         BatchNormLayer whose running averages this pass updates (the pass that sees the real minibatch)."""
         k = self.k
-        k.colstats(0, y, None, None, None, None, rows, C, stride, 0, self.ws_stats, min(256, rows), bn.sums)
+        k.colstats(0, y, None, None, None, None, rows, C, stride, 0, self._ws(rows, C), self._chunks(rows), bn.sums)
         if self.exact:
-            self.comm.all_reduce_sum(bn.sums)
+            self.comm.all_reduce_sum_ordered(bn.sums, k)
         bn.count = float(count_rows * (self.comm.world if self.exact else 1))
         k.bn_make_affine(bn.sums, bn.count, BN_EPS, gamma, beta, C, bn.mean, bn.inv_std, bn.scale, bn.shift)
         k.affine(y, a, bn.scale, bn.shift, rows, C, stride, act)
@@ -378,9 +427,9 @@ class Trainer:
 
     def _bn_backward(self, bn, dA, a, y, dy, rows, C, stride, act, gname, bname, want_w):
         k = self.k
-        k.colstats(1, dA, a, y, bn.mean, bn.inv_std, rows, C, stride, act, self.ws_stats, min(256, rows), bn.bsums)
+        k.colstats(1, dA, a, y, bn.mean, bn.inv_std, rows, C, stride, act, self._ws(rows, C), self._chunks(rows), bn.bsums)
         if self.exact:
-            self.comm.all_reduce_sum(bn.bsums)
+            self.comm.all_reduce_sum_ordered(bn.bsums, k)
         if want_w:
             # with exact statistics every rank already holds the GLOBAL dbeta/dgamma: pre-divide so that the
             # gradient all-reduce (a sum over ranks) restores them
@@ -710,7 +759,7 @@ class Trainer:
     def backward(self, which):
         """Gradients of the update rules of train_IAN.py:253-273 for ``which`` in {'gen', 'discrim'} (Z_params always)."""
         k, n, N, c = self.k, self.n, self.N, self.cfg
-        self.touched = set()
+        self._begin_backward(which)
         EX, EH, EG, DZ, DG, ZS = self.EX, self.EH, self.EG, self.DZ, self.DG, self.ZS
         gen = which == "gen"
         # ---- shared generator-side loss S = adv_gen + recon_weight*pixel + feature_weight*feature -----------------
@@ -757,15 +806,92 @@ class Trainer:
         a_t = self.lr * math.sqrt(1.0 - b2 ** g.t) / (1.0 - b1 ** g.t)
         self.k.adam(g.p, g.g, g.m, g.v, g.numel, a_t, b1, b2, 1e-8)
 
+    # ---------------------------------------------------------------------------------------------
+    # gradient all-reduce overlapped with backward
+    # ---------------------------------------------------------------------------------------------
+    # The flat gradient buffer of a group is cut into buckets.  A bucket may be reduced as soon as the last kernel that
+    # writes into it has been issued: encoder_params receive contributions from three encoder passes, decoder_params
+    # from two decoder passes, so "last" is a property of the whole backward sweep of a step kind.  The first step of
+    # each kind records the order of gradient writes (every write goes through ``self.touched``); from the second step
+    # on, the moment a bucket's last write is issued an event is recorded on the compute stream, a side stream waits
+    # for it and the bucket's all-reduce is issued there (RCCL runs it on its own stream behind the side stream), while
+    # the compute stream goes on with the rest of backward.  Z_params' bucket(s) finish before the second decoder /
+    # the encoder passes even start.  Before the regularisers and Adam the compute stream waits for all the works.
+    def _begin_backward(self, which):
+        self.touched = _WriteLog(self)
+        self._which, self._ev, self._evlog, self._fired, self._works = which, 0, [], set(), []
+        self._buckets = None
+        plan = self._plans.get(which) if (self.comm.world > 1 and self.overlap) else None
+        if plan is not None:
+            self._buckets = plan
+            for b in plan:
+                if b["ready"] == 0:
+                    self._fire(b)
+
+    def _wrote(self, names):
+        self._ev += 1
+        self._evlog.append(names)
+        if self._buckets is None:
+            return
+        for b in self._buckets:
+            if b["id"] in self._fired:
+                if any(nm in b["names"] for nm in names):
+                    raise IanTrainError("gradient of %s written after its bucket was handed to the all-reduce" % (names,))
+            elif b["ready"] == self._ev:
+                self._fire(b)
+
+    def _make_plan(self, which):
+        """Buckets of the groups this step kind updates, each with the index of its last gradient write."""
+        last = {}
+        for i, names in enumerate(self._evlog):
+            for nm in names:
+                last[nm] = i + 1
+        step = max(1, self.comm.bucket_bytes // 4)
+        plan = []
+        for gname in (("dec" if which == "gen" else "enc"), "Z"):
+            g = self.groups[gname]
+            for o in range(0, g.numel, step):
+                e = min(g.numel, o + step)
+                names = [nm for nm, (po, cnt, _) in g.offsets.items() if po < e and po + cnt > o]
+                plan.append({"id": (gname, o), "group": gname, "lo": o, "hi": e, "names": set(names),
+                             "ready": max([last.get(nm, 0) for nm in names] + [0])})
+        return plan
+
+    def _fire(self, b):
+        torch = self.torch
+        view = self.groups[b["group"]].g[b["lo"]:b["hi"]]
+        ev = torch.cuda.Event()
+        ev.record()                                   # after the bucket's last writer on the compute stream
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            w = self.comm.all_reduce_sum(view, async_op=True)
+        self._fired.add(b["id"])
+        self._works.append(w)
+        self.overlap_log.append({"which": self._which, "bucket": b["id"], "bytes": 4 * (b["hi"] - b["lo"]), "issued_at_write": self._ev})
+
+    def _finish_allreduce(self, which):
+        """After backward: reduce whatever has not been handed over yet, then make the compute stream wait."""
+        if self.comm.world == 1:
+            return
+        if self._buckets is None:                      # first step of this kind (or overlap off): plan, then reduce all
+            self._plans[which] = self._make_plan(which)
+            self._buckets = self._plans[which]
+        for b in self._buckets:
+            if b["id"] not in self._fired:
+                self._fire(b)
+        for rec in self.overlap_log[-len(self._works):]:
+            rec["writes_in_backward"] = self._ev
+        for w in self._works:
+            w.wait()                                   # RCCL: stream-level wait; gloo: host wait
+        self._works = []
+        self._buckets = None
+
     def step(self, which, X, Z, eps, return_metrics=True):
         upd = "dec" if which == "gen" else "enc"
         self.forward(X, Z, eps)
         m = self.metrics() if return_metrics else None
         self.backward(which)
-        if self.comm.world > 1:
-            self.torch.cuda.current_stream().synchronize()
-            for gname in (upd, "Z"):
-                self.comm.all_reduce_buckets(self.groups[gname].g)
+        self._finish_allreduce(which)
         self._regularizers(which)
         self._adam(upd)
         self._adam("Z")
