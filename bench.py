@@ -11,6 +11,8 @@ Extra fields in the same JSON line:
                 in a separate profiled pass of the same workload (event records perturb the timed pass);
   cpu_baseline  the torch-CPU twin of the oracle ("port": the reference's Theano path cannot run here),
                 rank 0, N=1 only, bounded sample;
+  step_ms       p50/p95 of the K timed steps (device time between consecutive steps);
+  full_ian      the same measurement for BASELINE.json configs[2]: full IAN, batch 256 per GPU, with its own roofline;
   edit_step     p50/p95 latency of one NPE latent-brush step (BASELINE.json configs[3]): imgradRGB +
                 Z update (reference gradient descent, NPE.py:199-209) + sample_at, batch 1.
 """
@@ -31,31 +33,62 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 FLOP_PER_RECON = {"IAN_simple": 2.592e9, "IAN": 8.463e9}
 
 
-def cpu_baseline(arch, P, batch, budget_s=20.0):
+def _cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "?"
+
+
+def cpu_baseline(arch, P, batch, budget_s=22.0):
+    """the torch-CPU restatement (NOT Theano) on this host, >=5 warm-up and >=20 timed passes
+    (or as many as the stated time budget allows, never fewer than 5), median and p95, batch 1 (1 thread and all
+    threads) and the GPU workload's batch.  When one pass at the GPU batch takes longer than 0.5 s the batch case
+    falls back to 16 images so that the whole baseline stays within ~budget_s seconds; the sample string says so."""
     import torch
     from oracle.torch_twin import TorchTwin      # the ONLY use of oracle/ in this file: the timed CPU baseline
     from neural_photo_editor_amd import synthetic as O
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     tw = TorchTwin(arch, P)
-    x = torch.from_numpy(O.make_images(batch, seed=0))
-    with torch.no_grad():
-        tw.decode(tw.encode(x))  # warm-up
-        t0 = time.time(); n = 0
-        while True:
-            tw.decode(tw.encode(x)); n += 1
-            if time.time() - t0 > budget_s or n >= 20:
-                break
-        dt = (time.time() - t0) / n
-    model = "?"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip(); break
-    except OSError:
-        pass
-    return {"value": batch / dt, "unit": "reconstructions/s", "cores": cores, "kind": "port",
-            "sample": "%d passes of batch %d through the torch-CPU restatement (not Theano), %s" % (n, batch, model)}
+
+    def run(b, threads, budget, min_timed=5, want=20):
+        torch.set_num_threads(threads)
+        x = torch.from_numpy(O.make_images(b, seed=0))
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            tw.decode(tw.encode(x))
+            first = time.perf_counter() - t0
+            warm = 1
+            while warm < 5 and (time.perf_counter() - t0) < 0.25 * budget:
+                tw.decode(tw.encode(x)); warm += 1
+            ts = []
+            t1 = time.perf_counter()
+            while len(ts) < want and (len(ts) < min_timed or time.perf_counter() - t1 < budget):
+                t = time.perf_counter(); tw.decode(tw.encode(x)); ts.append(time.perf_counter() - t)
+        ts = np.array(ts)
+        return {"batch": b, "threads": threads, "warmup": warm, "timed": len(ts), "p50_ms": float(np.percentile(ts, 50) * 1e3),
+                "p95_ms": float(np.percentile(ts, 95) * 1e3), "value": float(b / np.percentile(ts, 50)), "first_pass_ms": first * 1e3}
+
+    cases = [run(1, 1, 3.0), run(1, cores, 3.0)]
+    # thread count for the batched case: the fastest of {all, a quarter} logical CPUs on a short probe (oneDNN scales
+    # poorly past the physical core count on wide hosts)
+    probe_b = 16
+    cand = sorted({cores, max(1, cores // 4)}, reverse=True)
+    probes = {t: run(probe_b, t, 0.0, min_timed=1, want=1) for t in cand}
+    best_t = min(cand, key=lambda t: probes[t]["p50_ms"])
+    per_img = probes[best_t]["p50_ms"] / probe_b
+    b_main = batch if per_img * batch < 500.0 else probe_b
+    main = run(b_main, best_t, budget_s - 10.0)
+    cases.append(main)
+    note = "" if b_main == batch else " (one pass at batch %d would take ~%.1f s: batch %d used to keep the baseline within its time budget)" % (batch, per_img * batch / 1e3, b_main)
+    return {"value": main["value"], "unit": "reconstructions/s", "cores": best_t, "kind": "port",
+            "p50_ms": main["p50_ms"], "p95_ms": main["p95_ms"], "host_logical_cpus": cores, "cpu": _cpu_model_name(),
+            "sample": "%s encode->decode through the torch-CPU restatement (not Theano): %d warm-up + %d timed passes of batch %d on %d threads, median%s"
+                      % (arch, main["warmup"], main["timed"], b_main, best_t, note),
+            "cases": cases}
 
 
 def pmc_traffic(arch, B):
@@ -113,6 +146,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 64 for IAN_simple, 256 for IAN)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-edit", action="store_true")
+    ap.add_argument("--no-full-ian", action="store_true", help="skip the full-IAN batch-256 block (BASELINE.json configs[2])")
     ap.add_argument("--train", action="store_true", help="also time the train_IAN.py step (default: only on 1 GPU)")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-batch", type=int, default=128, help="per-GPU minibatch of the training step (config 5: 1024 over 8 GPUs)")
@@ -136,16 +170,6 @@ def main():
     from neural_photo_editor_amd import IAN
     from neural_photo_editor_amd import synthetic as O   # seeded synthetic parameters / images (no trained weights exist)
 
-    arch = args.arch
-    B = args.batch or (64 if arch == "IAN_simple" else 256)
-    P = O.make_params(arch, seed=1)
-    model = IAN(os.path.join(ROOT, "neural_photo_editor_amd", "configs", arch + ".py"), True, params=P)
-    h = model.handle
-    for kv in filter(None, os.environ.get("IAN_OPTS", "").split(",")):  # tuning knobs, e.g. IAN_OPTS=tg_cfg=0
-        k, v = kv.split("=")
-        h.set_option(k, int(v))
-    x = torch.from_numpy(O.make_images(B, seed=100 + rank)).cuda()
-    out = torch.empty_like(x)
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -154,46 +178,74 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        h.call("ian_reconstruct", x, B, out, stream=stream)
+    def measure(arch, B, steps, warmup):
+        """W warm-up + K timed reconstruction steps of `arch` at batch B (inputs resident in HBM); on rank 0 also the
+        profiled pass for the roofline.  -> (model, params, dict)"""
+        P = O.make_params(arch, seed=1)
+        model = IAN(os.path.join(ROOT, "neural_photo_editor_amd", "configs", arch + ".py"), True, params=P)
+        h = model.handle
+        for kv in filter(None, os.environ.get("IAN_OPTS", "").split(",")):  # tuning knobs, e.g. IAN_OPTS=tg_cfg=0
+            k, v = kv.split("=")
+            h.set_option(k, int(v))
+        x = torch.from_numpy(O.make_images(B, seed=100 + rank)).cuda()
+        out = torch.empty_like(x)
 
-    step()
-    if not os.environ.get("IAN_NO_AUTOTUNE"):
-        h.autotune(B, 1, stream=stream)  # untimed: pick tile shape / split-K per layer for this batch on this GPU
-    for _ in range(args.warmup):
+        def step():
+            h.call("ian_reconstruct", x, B, out, stream=stream)
+
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    ms_per_step = dt / args.steps * 1e3
-    value = world * B * args.steps / dt
+        if not os.environ.get("IAN_NO_AUTOTUNE"):
+            h.autotune(B, 1, stream=stream)  # untimed: pick tile shape / split-K per layer for this batch on this GPU
+        for _ in range(warmup):
+            step()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        barrier()
+        t0 = time.perf_counter()
+        evs[0].record()
+        for i in range(steps):
+            step()
+            evs[i + 1].record()          # device-side step boundaries: no host synchronisation inside the timed region
+        barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
+        r = {"ms_per_step": dt / steps * 1e3, "value": world * B * steps / dt,
+             "step_ms": {"p50": float(np.percentile(per, 50)), "p95": float(np.percentile(per, 95)), "min": float(per.min()),
+                         "max": float(per.max()), "how": "HIP events on the launch stream between consecutive steps (device time)"}}
+        if rank == 0:
+            # --- roofline: profiled pass (HIP events around every tapgemm launch, on the launch stream) ---
+            nprof = min(steps, 20)
+            h.profile_enable(True)
+            for _ in range(nprof):
+                step()
+            pr = h.profile_read()
+            h.profile_enable(False)
+            launches = max(pr["tapgemm_launches"], 1)
+            flops_per_launch = pr["tapgemm_flops"] / launches
+            avg_ms = pr["tapgemm_ms"] / launches
+            achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            traffic, traffic_src = pmc_traffic(arch, B)
+            r["roofline"] = {"bound": "mfma", "kernel": "tapgemm_kernel (fp32 v_mfma_f32_32x32x2_f32)", "achieved": achieved,
+                             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                             "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % traffic_src if traffic else None,
+                             "flop_per_launch": flops_per_launch, "launches_per_step": launches / nprof,
+                             "avg_launch_ms": avg_ms, "tapgemm_share_of_step": pr["tapgemm_ms"] / max(pr["total_ms"], 1e-9),
+                             "whole_step_tflops": FLOP_PER_RECON[arch] * B / (r["ms_per_step"] * 1e-3) / 1e12,
+                             "whole_step_frac_of_peak": FLOP_PER_RECON[arch] * B / (r["ms_per_step"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+        return model, P, r
+
+    arch = args.arch
+    B = args.batch or (64 if arch == "IAN_simple" else 256)
+    model, P, main_r = measure(arch, B, args.steps, args.warmup)
+    h = model.handle
+    ms_per_step, value = main_r["ms_per_step"], main_r["value"]
 
     result = None
     if rank == 0:
-        # --- roofline: profiled pass (HIP events around every tapgemm launch, on the launch stream) ---
-        h.profile_enable(True)
-        for _ in range(min(args.steps, 20)):
-            step()
-        pr = h.profile_read()
-        h.profile_enable(False)
-        launches = max(pr["tapgemm_launches"], 1)
-        flops_per_launch = pr["tapgemm_flops"] / launches
-        avg_ms = pr["tapgemm_ms"] / launches
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(arch, B)
-        roofline = {"bound": "mfma", "kernel": "tapgemm_kernel (fp32 v_mfma_f32_32x32x2_f32)", "achieved": achieved,
-                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                    "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % traffic_src if traffic else None,
-                    "flop_per_launch": flops_per_launch, "launches_per_step": launches / min(args.steps, 20),
-                    "avg_launch_ms": avg_ms, "tapgemm_share_of_step": pr["tapgemm_ms"] / max(pr["total_ms"], 1e-9),
-                    "whole_step_tflops": FLOP_PER_RECON[arch] * B / (ms_per_step * 1e-3) / 1e12}
+        roofline = main_r["roofline"]
         edit = None
         if arch == "IAN_simple" and not args.no_edit:
             z = O.make_latents(1, seed=2)
@@ -227,7 +279,7 @@ def main():
                     "includes": "host<->device copies of z, rgb, image"}
         host_io = None
         if args.host_io:
-            xh = x.cpu().numpy()
+            xh = O.make_images(B, seed=100 + rank)
             model.reconstruct(xh)
             t = time.perf_counter()
             for _ in range(10):
@@ -243,10 +295,25 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s encode->z->decode reconstruction, batch %d per GPU, inputs resident in HBM"
                                    % (arch, B), "parallelism": "replicas x%d (no data-path collective)" % world},
-            "roofline": roofline, "cpu_baseline": cpu, "edit_step": edit,
+            "step_ms": main_r["step_ms"], "roofline": roofline, "cpu_baseline": cpu, "edit_step": edit,
         }
         if host_io:
             result["host_io"] = host_io
+    # ---- BASELINE.json configs[2]: full IAN (MDC + RGB-Beta blocks), batch 256 per GPU, same protocol --------------
+    if arch == "IAN_simple" and not args.no_full_ian:
+        fsteps, fwarm = min(args.steps, 20), min(args.warmup, 5)
+        try:
+            fmodel, _, fr = measure("IAN", 256, fsteps, fwarm)
+            fmodel.close()
+            del fmodel
+            torch.cuda.empty_cache()
+            full = {"workload": "IAN (IAN.py: MDBLOCKs + RGB-Beta head + MADE/IAF) encode->z->decode reconstruction, batch 256 per GPU, inputs resident in HBM",
+                    "metric": "64x64 IAN reconstructions/sec", "value": fr["value"], "unit": "reconstructions/s", "steps": fsteps, "warmup": fwarm,
+                    "ms_per_step": fr["ms_per_step"], "step_ms": fr["step_ms"], "roofline": fr.get("roofline")}
+        except Exception as exc:
+            full = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        if rank == 0 and result is not None:
+            result["full_ian"] = full
     # ---- train_IAN.py step (BASELINE.json configs[4]): full IAN, data parallel, RCCL gradient all-reduce ----------
     train = None
     if (args.train or world == 1) and not args.no_train:

@@ -1,0 +1,315 @@
+"""GPU parity of the configurations round 1 never ran on hardware ("close the untested configurations"):
+
+  * the training building blocks and the composed update rules at the BENCHMARKED size -- 128 images per GPU -- where
+    tapwgrad's pixel-split schedule and ian_k_colstats' per-image chunking take the paths bench.py times;
+  * ``deconv_flip=False`` (the one convention that cannot be checked against Theano: SURVEY App. B.2) through the
+    inference path, the latent brush and a training layer;
+  * ``exact=False`` (data parallel with local batch statistics / local MinibatchLayer).
+
+References: float64 torch-CPU autograd (kernels), oracle/train_twin.py in float64 (composed gradients), the numpy oracle
+and torch twin with deconv_flip=False.  Measured error levels are written to gpurun_out/diag/ for the record.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ian_oracle as O
+from oracle.torch_twin import TorchTwin
+from oracle.train_twin import TrainTwin, make_train_params
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "neural_photo_editor_amd", "configs")
+NB = 128   # per-GPU batch of bench.py's train_step (BASELINE.json configs[4]: 1024 over 8 GPUs)
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(np.asarray(b)).max() + 1e-30))
+
+
+def diag(name, obj):
+    d = os.path.join(ROOT, "gpurun_out", "diag")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name + ".json"), "w") as fh:
+            json.dump(obj, fh, indent=1, default=lambda o: float(o))
+    except OSError:
+        pass
+
+
+def cs(c):
+    return (c + 31) // 32 * 32
+
+
+def to_nhwc(x):
+    n, c, h, w = x.shape
+    out = torch.zeros(n, h, w, cs(c))
+    out[..., :c] = torch.from_numpy(x).permute(0, 2, 3, 1)
+    return out.cuda()
+
+
+def from_nhwc(t, c):
+    return t.cpu().numpy()[..., :c].transpose(0, 3, 1, 2)
+
+
+@pytest.fixture(scope="module")
+def env():
+    from neural_photo_editor_amd.lib import load_train_library
+    from neural_photo_editor_amd import trainer as T
+    lib = load_train_library()
+    return lib, T, T.K(lib)
+
+
+# the layers of IAN.py whose backward-weight contraction (images x pixels) is longest at 128 images, one per kind,
+# at their real shapes: enc_conv2, dec_conv3, MDBLOCK dec_conv4a, the RGB-Beta head's R and G_b
+FULL_CASES = [
+    ("conv", dict(cin=128, cout=256, h=32)),
+    ("deconv", dict(cin=256, cout=128, h=16)),
+    ("mdc", dict(cin=128, cout=128, h=32, scales=[0, 2, 3])),
+    ("mdc", dict(cin=128, cout=2, h=64, scales=[2, 3, 4])),
+    ("mdc", dict(cin=2, cout=2, h=64, scales=[2, 3, 4])),
+]
+
+
+@pytest.mark.parametrize("kind,g", FULL_CASES)
+def test_layers_at_the_benchmarked_batch(env, kind, g):
+    """forward / backward-data / backward-weight of one layer of each kind on 128 images vs float64 autograd."""
+    lib, T, k = env
+    n = NB
+    rs = np.random.RandomState(hash((kind, g["cin"], g["cout"])) % 2 ** 31)
+    cin, cout, h = g["cin"], g["cout"], g["h"]
+    x = rs.randn(n, cin, h, h).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    if kind == "conv":
+        W = (rs.randn(cout, cin, 5, 5) * 0.02).astype(np.float32)
+        params = [torch.tensor(W, dtype=torch.float64, requires_grad=True)]
+        y = F.conv2d(xt, params[0], stride=2, padding=2)
+        layer = T.Layer(lib, T.K_CONV, cin, cout, h, h)
+    elif kind == "deconv":
+        W = (rs.randn(cin, cout, 5, 5) * 0.02).astype(np.float32)
+        params = [torch.tensor(W, dtype=torch.float64, requires_grad=True)]
+        y = F.conv_transpose2d(xt, torch.flip(params[0], (2, 3)), stride=2, padding=2, output_padding=1)
+        layer = T.Layer(lib, T.K_DECONV, cin, cout, h, h)
+    else:
+        sc = g["scales"]
+        W = (rs.randn(cout, cin, 3, 3) * 0.05).astype(np.float32)
+        coeffs = [rs.uniform(0.5, 1.5, cout).astype(np.float32) for _ in range(1 + len(sc))]
+        params = [torch.tensor(W, dtype=torch.float64, requires_grad=True)] + [torch.tensor(c, dtype=torch.float64, requires_grad=True) for c in coeffs]
+        y = F.conv2d(xt, params[0], padding=1) * params[1].reshape(1, -1, 1, 1)
+        for i, s in enumerate(sc):
+            cf = params[2 + i].reshape(1, -1, 1, 1)
+            y = y + (F.conv2d(xt, params[0].mean((2, 3), keepdim=True)) if s == 0 else F.conv2d(xt, params[0], padding=s, dilation=s)) * cf
+        layer = T.Layer(lib, T.K_MDC, cin, cout, h, h, scales=sc)
+    dy = rs.randn(*y.shape).astype(np.float32)
+    gx, *gp = torch.autograd.grad(y, [xt] + params, torch.tensor(dy, dtype=torch.float64))
+    layer.set_params([torch.from_numpy(p.detach().numpy().astype(np.float32).ravel()).cuda() for p in params])
+    oh = y.shape[2]
+    xd, dyd = to_nhwc(x), to_nhwc(dy)
+    yd = torch.zeros(n, oh, oh, cs(cout), device="cuda")
+    layer.forward(xd, n, yd)
+    e = {"fwd": rel(from_nhwc(yd, cout), y.detach().numpy())}
+    dxd = torch.zeros(n, h, h, cs(cin), device="cuda")
+    layer.backward_data(dyd, n, dxd)
+    e["bwd_data"] = rel(from_nhwc(dxd, cin), gx.numpy())
+    dp = [torch.zeros(int(np.prod(p.shape)), device="cuda") for p in params]
+    layer.backward_weight(xd, dyd, n, dp)
+    e["bwd_weight"] = max(rel(got.cpu().numpy().reshape(ref.shape), ref.numpy()) for got, ref in zip(dp, gp))
+    layer.backward_weight(xd, dyd, n, dp, accumulate=True)
+    e["bwd_weight_acc"] = rel(dp[0].cpu().numpy().reshape(gp[0].shape), 2 * gp[0].numpy())
+    layer.close()
+    diag("layer128_%s_%d_%d" % (kind, cin, cout), e)
+    assert e["fwd"] < 2e-5 and e["bwd_data"] < 2e-5, e
+    # a contraction over 128 x (16..64)^2 pixels in float32: round-off grows with sqrt(K)
+    assert e["bwd_weight"] < 1e-4 and e["bwd_weight_acc"] < 1e-4, e
+
+
+@pytest.mark.parametrize("rows_per_image,C,act", [(4096, 128, 2), (16, 1024, 2), (1, 1000, 1)])
+def test_batch_norm_at_the_benchmarked_batch(env, rows_per_image, C, act):
+    """Lasagne batch_norm training mode (App. B.3) forward + backward over 128 images with the trainer's chunk rule."""
+    lib, T, k = env
+    n = NB
+    rows, stride = n * rows_per_image, cs(C)
+    rs = np.random.RandomState(C + rows_per_image)
+    y = (rs.randn(rows, C) * rs.uniform(0.5, 2, C) + rs.randn(C)).astype(np.float32)
+    gamma, beta = rs.uniform(0.5, 1.5, C).astype(np.float32), rs.randn(C).astype(np.float32)
+    dA = rs.randn(rows, C).astype(np.float32)
+    yt, gt, bt = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (y, gamma, beta)]
+    mean, var = yt.mean(0), yt.var(0, unbiased=False)
+    pre = (yt - mean) / torch.sqrt(var + 1e-4) * gt + bt
+    a = F.leaky_relu(pre, 0.2) if act == 2 else torch.relu(pre)
+    gy, gg, gb = torch.autograd.grad(a, [yt, gt, bt], torch.tensor(dA, dtype=torch.float64))
+    pad = lambda v: torch.from_numpy(np.pad(v, ((0, 0), (0, stride - C)))).cuda()
+    yd, dAd = pad(y), pad(dA)
+    ad = torch.zeros_like(yd)
+    bn = T.BN(torch, C, "cuda")
+    nch = n * max(1, rows_per_image // 512)
+    ws = torch.zeros(nch * 2 * C, device="cuda")
+    k.colstats(0, yd, None, None, None, None, rows, C, stride, 0, ws, nch, bn.sums)
+    k.bn_make_affine(bn.sums, float(rows), 1e-4, torch.from_numpy(gamma).cuda(), torch.from_numpy(beta).cuda(), C, bn.mean, bn.inv_std, bn.scale, bn.shift)
+    k.affine(yd, ad, bn.scale, bn.shift, rows, C, stride, act)
+    e = {"fwd": rel(ad.cpu().numpy()[:, :C], a.detach().numpy())}
+    k.colstats(1, dAd, ad, yd, bn.mean, bn.inv_std, rows, C, stride, act, ws, nch, bn.bsums)
+    dyd = torch.zeros_like(yd)
+    k.bn_bwd(dAd, ad, yd, bn.mean, bn.inv_std, bn.scale, bn.bsums, float(rows), dyd, rows, C, stride, act)
+    s = bn.bsums.cpu().numpy()
+    e.update(dbeta=rel(s[:C], gb.numpy()), dgamma=rel(s[C:], gg.numpy()), dy=rel(dyd.cpu().numpy()[:, :C], gy.numpy()))
+    diag("bn128_%d_%d" % (rows_per_image, C), e)
+    assert e["fwd"] < 2e-5 and e["dbeta"] < 1e-4 and e["dgamma"] < 1e-4 and e["dy"] < 1e-4, e
+
+
+def test_composed_updates_at_the_benchmarked_batch():
+    """update_gen / update_discrim gradients on 128 images vs the float64 twin (encoder passes on X_hat / X_gen are fed
+    the twin's images, as in test_gpu_train.test_gradients_match_autograd).  With 128-image batch statistics the float32
+    conditioning is far better than at 4 images; the bars are absolute."""
+    from neural_photo_editor_amd.trainer import Trainer
+    P = make_train_params(O.make_params("IAN", 1))
+    X, Z = O.make_images(NB, seed=31), O.make_latents(NB, seed=32)
+    eps = np.random.RandomState(33).randn(NB, 100).astype(np.float32)
+    tw = TrainTwin(P, dtype=torch.float64)
+    g64, _ = tw.gradients(X, Z, eps)
+    xh, xg = [t.detach().numpy().astype(np.float32) for t in (tw.tensors["X_hat"], tw.tensors["X_gen"])]
+    tr = Trainer(os.path.join(CFG, "IAN.py"), P, batch=NB)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out = {}
+    for which in ("gen", "discrim"):
+        tr.forward(dev(X), dev(Z), dev(eps), xhat_override=dev(xh), xgen_override=dev(xg))
+        tr.backward(which)
+        tr._regularizers(which)
+        for gname in (("dec", "Z") if which == "gen" else ("enc", "Z")):
+            got = tr.grads_numpy(gname)
+            errs = sorted(((rel(got[name], ref.numpy()), name) for name, ref in g64[gname].items()), reverse=True)
+            out["%s/%s" % (which, gname)] = {"median": float(np.median([e for e, _ in errs])), "worst": errs[:5]}
+    diag("composed128", out)
+    for key, v in out.items():
+        assert v["median"] < 1e-3 and v["worst"][0][0] < 2e-2, (key, v)
+
+
+# ---- deconv_flip = False --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("arch", O.ARCHS)
+def test_deconv_flip_false_inference_and_brush(arch):
+    """The kernel-flip switch of DeconvLayer (layers.py:476-481) set the other way: decoder, brush
+    gradients and the edge (dec_out) kernels must follow the oracle built with deconv_flip=False, and must differ
+    from the default convention (the switch is live)."""
+    from neural_photo_editor_amd import IAN
+    P = O.make_params(arch, 1)
+    m = IAN(os.path.join(CFG, arch + ".py"), True, params=P, deconv_flip=False)
+    orc = O.Oracle(arch, P, deconv_flip=False)
+    z = O.make_latents(3, seed=21)
+    x = O.make_images(3, seed=22)
+    ref = orc.sample_at(z)
+    assert rel(m.sample_at(z), ref) < 1e-4
+    assert rel(m.reconstruct(x), orc.reconstruct(x)) < 1e-4
+    assert rel(O.Oracle(arch, P).sample_at(z), ref) > 1e-2          # the two conventions give different images
+    tw = TorchTwin(arch, P, deconv_flip=False, dtype=torch.float64)
+    rgb = np.random.RandomState(5).uniform(-1, 1, (1, 3, 64, 64)).astype(np.float32)
+    for patch in ((26, 26, 30, 30), (0, 0, 64, 64), (60, 0, 64, 9)):
+        assert rel(m.imgradRGB(*patch, rgb, z[:1]), tw.imgradRGB(*patch, rgb, z[:1])) < 5e-4
+        assert rel(m.imgrad(*patch, z[:1]), tw.imgrad(*patch, z[:1])) < 5e-4
+    m.close()
+
+
+def test_deconv_flip_false_training_layer(env):
+    lib, T, k = env
+    n, cin, cout, h = 5, 64, 32, 8
+    rs = np.random.RandomState(12)
+    x = rs.randn(n, cin, h, h).astype(np.float32)
+    W = (rs.randn(cin, cout, 5, 5) * 0.1).astype(np.float32)
+    xt, wt = torch.tensor(x, dtype=torch.float64, requires_grad=True), torch.tensor(W, dtype=torch.float64, requires_grad=True)
+    y = F.conv_transpose2d(xt, wt, stride=2, padding=2, output_padding=1)        # no kernel flip
+    dy = rs.randn(*y.shape).astype(np.float32)
+    gx, gw = torch.autograd.grad(y, [xt, wt], torch.tensor(dy, dtype=torch.float64))
+    layer = T.Layer(lib, T.K_DECONV, cin, cout, h, h, deconv_flip=False)
+    layer.set_params([torch.from_numpy(W.ravel()).cuda()])
+    xd, dyd = to_nhwc(x), to_nhwc(dy)
+    yd = torch.zeros(n, 2 * h, 2 * h, cs(cout), device="cuda")
+    layer.forward(xd, n, yd)
+    assert rel(from_nhwc(yd, cout), y.detach().numpy()) < 2e-5
+    dxd = torch.zeros(n, h, h, cs(cin), device="cuda")
+    layer.backward_data(dyd, n, dxd)
+    assert rel(from_nhwc(dxd, cin), gx.numpy()) < 2e-5
+    dW = [torch.zeros(W.size, device="cuda")]
+    layer.backward_weight(xd, dyd, n, dW)
+    assert rel(dW[0].cpu().numpy().reshape(W.shape), gw.numpy()) < 2e-5
+    layer.close()
+
+
+def test_deconv_flip_false_training_step_matches_twin():
+    """One composed generator sweep with the other kernel convention (decoder_params gradients depend on it)."""
+    from neural_photo_editor_amd.trainer import Trainer
+    B = 4
+    P = make_train_params(O.make_params("IAN", 1))
+    X, Z = O.make_images(B, seed=1), O.make_latents(B, seed=6)
+    eps = np.random.RandomState(7).randn(B, 100).astype(np.float32)
+    tw = TrainTwin(P, dtype=torch.float64, deconv_flip=False)
+    g64, _ = tw.gradients(X, Z, eps)
+    xh, xg = [t.detach().numpy().astype(np.float32) for t in (tw.tensors["X_hat"], tw.tensors["X_gen"])]
+    tr = Trainer(os.path.join(CFG, "IAN.py"), P, batch=B, deconv_flip=False)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    tr.forward(dev(X), dev(Z), dev(eps), xhat_override=dev(xh), xgen_override=dev(xg))
+    assert rel(tr.DZ["xhat"].cpu().numpy(), tw.tensors["X_hat"].detach().numpy()) < 1e-4
+    tr.backward("gen")
+    tr._regularizers("gen")
+    got = tr.grads_numpy("dec")
+    errs = sorted(((rel(got[name], ref.numpy()), name) for name, ref in g64["dec"].items()), reverse=True)
+    diag("flip_false_gen", {"median": float(np.median([e for e, _ in errs])), "worst": errs[:5]})
+    assert float(np.median([e for e, _ in errs])) < 5e-3 and errs[0][0] < 0.2, errs[:5]
+    tw2 = TrainTwin(P, dtype=torch.float64)                                         # default convention: a different function
+    tw2.losses(X, Z, eps)
+    assert rel(tw2.tensors["X_hat"].detach().numpy(), tw.tensors["X_hat"].detach().numpy()) > 1e-2
+
+
+# ---- exact = False ----------------------------------------------------------------------------------------------------
+class _LocalComm:
+    """A 2-rank communicator whose collectives are identities: what rank 0 computes BEFORE the gradient sum."""
+    active, world, rank, group, bucket_bytes = True, 2, 0, None, 16 << 20
+
+    def all_reduce_sum(self, t, async_op=False):
+        class _W:
+            def wait(self):
+                pass
+        return _W()
+
+    def all_reduce_sum_ordered(self, t, k):
+        raise AssertionError("exact=False must not all-reduce batch statistics")
+
+    def all_gather_rows(self, local, out):
+        raise AssertionError("exact=False must not all-gather MinibatchLayer activations")
+
+    def all_reduce_buckets(self, flat, async_op=False):
+        return []
+
+    def barrier(self):
+        pass
+
+
+@pytest.mark.parametrize("which", ["gen", "discrim"])
+def test_local_statistics_mode(which):
+    """exact=False (train_cli --local-statistics): batch-norm statistics and the MinibatchLayer see only the rank's own
+    shard; losses are still means over the GLOBAL minibatch, so a rank's pre-reduction gradient is n/N times the
+    single-process gradient of its shard.  Checked against a world-1 trainer on the same 4 images: factor 1/2 exactly
+    (a power of two: bitwise), for every tensor of the updated groups."""
+    from neural_photo_editor_amd.trainer import Trainer
+    B = 4
+    P = make_train_params(O.make_params("IAN", 1))
+    X, Z = O.make_images(B, seed=2), O.make_latents(B, seed=3)
+    eps = np.random.RandomState(4).randn(B, 100).astype(np.float32)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    single = Trainer(os.path.join(CFG, "IAN.py"), P, batch=B)
+    local = Trainer(os.path.join(CFG, "IAN.py"), P, batch=B, comm=_LocalComm(), exact=False)
+    assert local.N == 2 * B and not local.exact and single.N == B
+    for tr in (single, local):
+        tr.forward(dev(X), dev(Z), dev(eps))
+        tr.backward(which)
+        tr._finish_allreduce(which)
+    assert torch.equal(single.DZ["xhat"], local.DZ["xhat"]) and torch.equal(single.EG["p"], local.EG["p"])
+    for g in (("dec" if which == "gen" else "enc"), "Z"):
+        a, b = single.groups[g].g, local.groups[g].g
+        assert float(a.abs().max()) > 0
+        assert torch.allclose(0.5 * a, b, rtol=1e-6, atol=0), g
+    ms, ml = single.metrics(), local.metrics()
+    assert abs(ms["pixel_loss"] - 2 * ml["pixel_loss"]) < 1e-6 * abs(ms["pixel_loss"])      # half of the global mean lives on each rank
