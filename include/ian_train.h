@@ -39,7 +39,9 @@ int ian_layer_create(const ian_op_desc* desc, int32_t deconv_flip, ian_layer** o
 int32_t ian_layer_num_params(ian_layer* l);
 int64_t ian_layer_param_numel(ian_layer* l, int32_t which);
 /* (Re)pack the current parameter values (device pointers, reference layout) into the kernel layouts.  Call after
-   every optimiser update. */
+   every optimiser update.  LIFETIME: an MDCL layer keeps the pointers -- its backward-weight reads W and the branch
+   coefficients again (dW = sum_b coeff_b * dS, dcoeff_b = <dS, W>) -- so the parameter buffers must stay valid (and hold
+   the values of this call) until the next ian_layer_set_params / ian_layer_destroy. */
 int ian_layer_set_params(ian_layer* l, const float* const* params, int32_t nparams, void* stream);
 /* y = act(x (*) W + bias + res).  bias / res may be NULL; bias is indexed by output channel (internal order).
    y_stride: pixel stride of y (0 = round_up(cout,32)). */

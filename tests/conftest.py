@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the CPU oracles (torch twins) run on the host cores: on a wide host (256 logical CPUs on the MI355X box) torch's
+    # default of one thread per logical CPU is catastrophically oversubscribed for these 64x64 convolutions
+    # (measured: batch-1 reconstruction 53 ms on 1 thread, 6 s on 256 threads) -- cap it
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    except Exception:
+        pass
 
 
 def _gpu_present():

@@ -107,7 +107,10 @@ def test_layers_at_the_benchmarked_batch(env, kind, g):
         layer = T.Layer(lib, T.K_MDC, cin, cout, h, h, scales=sc)
     dy = rs.randn(*y.shape).astype(np.float32)
     gx, *gp = torch.autograd.grad(y, [xt] + params, torch.tensor(dy, dtype=torch.float64))
-    layer.set_params([torch.from_numpy(p.detach().numpy().astype(np.float32).ravel()).cuda() for p in params])
+    # the layer keeps the parameter POINTERS (an MDCL's backward-weight reads W and the coefficients again): the tensors
+    # must outlive the layer's use of them (include/ian_train.h, ian_layer_set_params)
+    dev_params = [torch.from_numpy(p.detach().numpy().astype(np.float32).ravel()).cuda() for p in params]
+    layer.set_params(dev_params)
     oh = y.shape[2]
     xd, dyd = to_nhwc(x), to_nhwc(dy)
     yd = torch.zeros(n, oh, oh, cs(cout), device="cuda")
@@ -162,31 +165,71 @@ def test_batch_norm_at_the_benchmarked_batch(env, rows_per_image, C, act):
     assert e["fwd"] < 2e-5 and e["dbeta"] < 1e-4 and e["dgamma"] < 1e-4 and e["dy"] < 1e-4, e
 
 
-def test_composed_updates_at_the_benchmarked_batch():
-    """update_gen / update_discrim gradients on 128 images vs the float64 twin (encoder passes on X_hat / X_gen are fed
-    the twin's images, as in test_gpu_train.test_gradients_match_autograd).  With 128-image batch statistics the float32
-    conditioning is far better than at 4 images; the bars are absolute."""
+def test_generator_update_at_the_benchmarked_batch():
+    """update_gen's gradients (decoder_params, Z_params: train_IAN.py:256-273) on 128 images vs float64 autograd of the
+    twin; the encoder passes on X_hat / X_gen are fed the twin's images, as in test_gpu_train.test_gradients_match_autograd.
+    Measured on MI355X (gpurun_out/diag/composed128.json, round 2): median 5e-5 / worst 9e-3 (decoder), 5e-5 (Z)."""
     from neural_photo_editor_amd.trainer import Trainer
     P = make_train_params(O.make_params("IAN", 1))
     X, Z = O.make_images(NB, seed=31), O.make_latents(NB, seed=32)
     eps = np.random.RandomState(33).randn(NB, 100).astype(np.float32)
     tw = TrainTwin(P, dtype=torch.float64)
-    g64, _ = tw.gradients(X, Z, eps)
+    c = tw.cfg
+    L = tw.losses(X, Z, eps)
+    gen_loss = L["adv_gen"] + c["recon_weight"] * L["pixel_loss"] + c["feature_weight"] * L["feature_loss"] + L["l2_gen"]
+    z_loss = c["feature_weight"] * L["feature_loss"] + c["recon_weight"] * L["pixel_loss"] + L["adv_gen"] + L["kl_div"] + L["l2_Z"]
+    names = {"dec": list(tw.groups["dec"]), "Z": list(tw.groups["Z"])}
+    g_dec = torch.autograd.grad(gen_loss, [tw.P[n] for n in names["dec"]], retain_graph=True)
+    g_z = torch.autograd.grad(z_loss, [tw.P[n] for n in names["Z"]])
+    ref = {"dec": dict(zip(names["dec"], g_dec)), "Z": dict(zip(names["Z"], g_z))}
     xh, xg = [t.detach().numpy().astype(np.float32) for t in (tw.tensors["X_hat"], tw.tensors["X_gen"])]
     tr = Trainer(os.path.join(CFG, "IAN.py"), P, batch=NB)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    tr.forward(dev(X), dev(Z), dev(eps), xhat_override=dev(xh), xgen_override=dev(xg))
+    m = tr.metrics()
+    for k in ("pixel_loss", "kl_div", "feature_loss", "gen_recon_loss", "gen_sample_loss", "discrim_d_loss"):
+        assert abs(m[k] - float(L[k])) <= 2e-4 * max(1.0, abs(float(L[k]))), (k, m[k], float(L[k]))
+    tr.backward("gen")
+    tr._regularizers("gen")
     out = {}
-    for which in ("gen", "discrim"):
-        tr.forward(dev(X), dev(Z), dev(eps), xhat_override=dev(xh), xgen_override=dev(xg))
-        tr.backward(which)
-        tr._regularizers(which)
-        for gname in (("dec", "Z") if which == "gen" else ("enc", "Z")):
-            got = tr.grads_numpy(gname)
-            errs = sorted(((rel(got[name], ref.numpy()), name) for name, ref in g64[gname].items()), reverse=True)
-            out["%s/%s" % (which, gname)] = {"median": float(np.median([e for e, _ in errs])), "worst": errs[:5]}
+    for gname in ("dec", "Z"):
+        got = tr.grads_numpy(gname)
+        errs = sorted(((rel(got[name], r.numpy()), name) for name, r in ref[gname].items()), reverse=True)
+        out[gname] = {"median": float(np.median([e for e, _ in errs])), "worst": errs[:5]}
     diag("composed128", out)
-    for key, v in out.items():
-        assert v["median"] < 1e-3 and v["worst"][0][0] < 2e-2, (key, v)
+    assert out["dec"]["median"] < 5e-4 and out["dec"]["worst"][0][0] < 3e-2, out["dec"]
+    assert out["Z"]["median"] < 5e-4 and out["Z"]["worst"][0][0] < 1e-3, out["Z"]
+
+
+def test_encoder_passes_at_the_benchmarked_batch():
+    """encoder_params gradients of one discriminator pass on 128 well-separated images (cross-entropy seeds through the
+    3-way head, MinibatchLayer over 128 samples, three batch-normalised strided convs) vs float64 autograd: the sharp form
+    of update_discrim's building block (test_gpu_train.test_encoder_passes_backward_sharp) at the benchmarked size."""
+    from oracle.train_twin import ENC_PARAMS
+    from neural_photo_editor_amd.trainer import Trainer
+    P = make_train_params(O.make_params("IAN", 1))
+    tr = Trainer(os.path.join(CFG, "IAN.py"), P, batch=NB)
+    tw = TrainTwin(P, dtype=torch.float64)
+    rs = np.random.RandomState(5)
+    s = rs.uniform(0.15, 1.0, (NB, 1, 1, 1)).astype(np.float32)
+    o = rs.uniform(-0.6, 0.3, (NB, 1, 1, 1)).astype(np.float32)
+    imgs = [np.clip(O.make_images(NB, seed=60 + i) * s + o, -1, 1).astype(np.float32) for i in range(3)]
+    Z, eps = O.make_latents(NB, seed=7), np.random.RandomState(8).randn(NB, 100).astype(np.float32)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    tr.forward(dev(imgs[0]), dev(Z), dev(eps), xhat_override=dev(imgs[1]), xgen_override=dev(imgs[2]))
+    enc = [tw.P[n] for n in ENC_PARAMS]
+    out = {}
+    for E, img, t in ((tr.EX, imgs[0], 0), (tr.EG, imgs[2], 2)):
+        g = tw.encoder(torch.tensor(img, dtype=torch.float64))
+        p = tw.discriminator(g[3])
+        ref = torch.autograd.grad((-torch.log(p[:, t])).mean(), enc)
+        tr.touched = set()
+        tr.enc_backward(E, (t, 1.0 / tr.N, -1, 0.0), False, True, False)
+        got = tr.grads_numpy("enc")
+        errs = sorted(((rel(got[n], r.numpy()), n) for n, r in zip(ENC_PARAMS, ref)), reverse=True)
+        out["target%d" % t] = errs[:4]
+        assert errs[0][0] < 5e-4, (t, errs[:4])
+    diag("encoder128", out)
 
 
 # ---- deconv_flip = False --------------------------------------------------------------------------------------------
