@@ -132,6 +132,22 @@ int ian_grad_rgb(ian_handle* h, int32_t c1, int32_t r1, int32_t c2, int32_t r2, 
 int ian_grad_light(ian_handle* h, int32_t c1, int32_t r1, int32_t c2, int32_t r2, const float* z, float* dz,
                    void* stream);
 
+/* ---- the steps NPE.py runs right after the hot path on every edit, chained after the decoder ---- */
+/* NPE.py:110,261 (update_photo, RECON): np.uint8(from_tanh(sample_at(z))) -> out u8[n,3,64,64]; the float image stays
+   on the device, 12 KB per image cross the bus.  Bare cast as in the reference: truncation toward zero, modulo 256. */
+int ian_decode_u8(ian_handle* h, const float* z, int32_t n, uint8_t* out, void* stream);
+/* NPE.py:218-231 (NPE.paint, photo mode), for the latent z (f32[1,num_latents]):
+     DELTA = sample_at(z)[0] - to_tanh(float32(RECON))
+     MASK  = scipy.ndimage.gaussian_filter(min(mean_c |DELTA|, 1), sigma)          float64, 'reflect', truncate 4
+     IM    = uint8(from_tanh(to_tanh(RECON) + MASK*DELTA + (1-MASK)*ERROR))
+   recon u8[3,64,64], error f32[3,64,64] (host or device; host copies are re-uploaded only when their bytes change),
+   gauss_half f64[radius+1] = scipy's normalised 1-D Gaussian from the centre outwards (the host computes it exactly as
+   scipy does: npe_ops.gaussian_half_kernel), radius <= 7.  im u8[3,64,64]; mask f64[64,64] or NULL.  Bit-exact with the
+   numpy/scipy expression (tests/test_gpu_npe.py).  Reuses the decoder activations of the last ian_decode /
+   ian_grad_* call on the same host latent. */
+int ian_photo_blend(ian_handle* h, const float* z, const uint8_t* recon, const float* error, const double* gauss_half,
+                    int32_t radius, uint8_t* im, double* mask, void* stream);
+
 /* Introspection used by tests, bench.py and profiling (not part of the reference surface). */
 /* Copy the activation of tensor slot `slot` from the last call, converted to NCHW, into out (host or device). */
 int ian_read_slot(ian_handle* h, int32_t slot, int32_t n, float* out, void* stream);

@@ -112,6 +112,29 @@ class IAN:
         """API.py:98-110: n x zdim -> n x 3 x 64 x 64."""
         return self._run("ian_decode", self._f32(z, (self._zdim,), "z"), (3, 64, 64))
 
+    # ---- what NPE.py does with the decoder output on every edit, on the device (SURVEY 8f rank 2) ----------
+    def sample_at_uint8(self, z):
+        """np.uint8(from_tanh(sample_at(z))) as in NPE.py:110,261 (update_photo, RECON): n x zdim -> uint8 n x 3 x 64 x 64;
+        the float image never leaves the device."""
+        z = self._f32(z, (self._zdim,), "z")
+        out = np.empty((z.shape[0], 3, 64, 64), np.uint8)
+        self._h.call("ian_decode_u8", z, z.shape[0], out)
+        return out
+
+    def photo_blend(self, z, recon_uint8, error, sigma=0.7):
+        """NPE.paint's photo-mode blend (NPE.py:218-231) chained after the decoder on the device:
+        -> (IM uint8 (3,64,64), MASK float64 (64,64)), bit-exact with the numpy/scipy expression (npe_ops.photo_blend_host)."""
+        from . import npe_ops
+        z = self._f32(z, (self._zdim,), "z")
+        recon = np.ascontiguousarray(recon_uint8, dtype=np.uint8)
+        err = np.ascontiguousarray(error, dtype=np.float32)
+        if recon.shape != (3, 64, 64) or err.shape != (3, 64, 64):
+            raise ValueError("RECON and ERROR must have shape (3,64,64)")
+        half = npe_ops.gaussian_half_kernel(sigma, int(4.0 * float(sigma) + 0.5))
+        im, mask = np.empty((3, 64, 64), np.uint8), np.empty((64, 64), np.float64)
+        self._h.photo_blend(z[:1], recon, err, half, im, mask)
+        return im, mask
+
     # ---- sample_IAN.py function equivalents (SURVEY M3) ----------------------------------------------
     def sampleZ(self, z):
         """sample_IAN.py:88: l_Z -> l_out (same as sample_at)."""

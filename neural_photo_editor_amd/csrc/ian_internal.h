@@ -164,6 +164,43 @@ struct MdcHeadWgradArgs {
 };
 hipError_t launch_mdc_head_wgrad(const MdcHeadWgradArgs& a, int nblocks, int Cin, int Cout, float* dS, int f_rows,
                                  int f_cols, hipStream_t s);
+// RGB-Beta head in two launches (kernels_head.hip).  head6: the six filters that read the 128-channel map (three
+// 2-filter MDCL layers with one tap list) -> compact [n][H][W][8] map (filters 0..5, 2 floats padding).
+struct HeadFusedArgs {
+  const float* x;          // NHWC, pixel stride xs, 128 channels
+  const float *w0, *w1, *w2;  // forward slabs [tap][CoutPad][128] of the three layers (rows 0,1 used)
+  float* out;              // compact map
+  const int* itab;         // [0..8] taps per dy = -4..4; [16 + 12*dyi + q] tap ids; [128 + t] dx of tap t
+  const float* ftab;       // [0..5] scale, [8..13] shift, [16..21] activation code of the six filters
+  int H, W, xs, ntaps, bands, halo;
+  long long w_tap_stride;
+};
+hipError_t launch_head6(const HeadFusedArgs& a, int n, hipStream_t s);
+struct HeadTailArgs {
+  const float* comp;       // compact map: (R0,R1,Ga0,Ga1,Ba0,Ba1,-,-) per pixel
+  const float *w_gb, *w_bb;  // forward slabs of G_b (2 in) and B_b (4 in): [tap][CoutPad][CinPad]
+  float* out;              // NCHW [n][3][H][W]
+  long long gb_tap_stride, bb_tap_stride;
+  int gb_cin, bb_cin;      // CinPad of the two slabs
+  float scale_g[2], shift_g[2], scale_b[2], shift_b[2];
+  int act_g, act_b, H, W, ntaps;
+  signed char dy[48], dx[48];
+};
+hipError_t launch_head_tail(const HeadTailArgs& a, int n, hipStream_t s);
+
+// NPE.paint's photo blend and the uint8 image conversion on the device (kernels_npe.hip; NPE.py:218-231, 110, 261)
+struct PhotoBlendArgs {
+  const float* xhat;           // decoder output, NCHW [3][64][64]
+  const unsigned char* recon;  // RECON uint8 [3][64][64]
+  const float* error;          // ERROR float32 [3][64][64]
+  unsigned char* im;           // IM uint8 [3][64][64]
+  double* mask;                // MASK float64 [64][64] or nullptr
+  double w[8];                 // Gaussian weights, centre outwards (scipy _gaussian_kernel1d)
+  int radius;
+};
+hipError_t launch_photo_blend(const PhotoBlendArgs& a, hipStream_t s);
+hipError_t launch_to_uint8(const float* x, unsigned char* y, long long n, hipStream_t s);
+
 // identity-edge gradient hand-over: gd[p,c] (+)= gs[p,coff+c] * act'(y[p,c]) * scale[c]   (NHWC, strides ss / ds)
 hipError_t launch_grad_pass(const float* gs, int ss, int coff, float* gd, const float* y, int ds, const float* scale,
                             long long npix, int C, int act, int accumulate, hipStream_t s);

@@ -111,6 +111,20 @@ struct Options {
   int tg_nosplit_min_out = 1 << 30;  // outputs (M*Cout) above which 64x64 is forced even if it under-fills
   int mdc_head = 2;                  // few-filter MDCL layers: 0 = tapgemm, 1 = VALU head kernel, 2 = + sibling layers fused
   int tg_variant = 2;                // K-loop schedule of tapgemm_kernel (kernels_tapgemm.hip); autotune picks per layer
+  int head_fused = 1;                // RGB-Beta head as head6 + head_tail (kernels_head.hip) when the graph matches IAN.py:183-207
+  int head_fused_min_n = 8;          // ... for batches of at least this many images (the latent brush's batch-1 backward
+                                     // needs the per-layer activations of the unfused ops)
+};
+
+// IAN.py:183-207 recognised in the lowered decoder: op indices of R, G_a, G_b, B_a, B_b, the [R,G] concat and the beta op
+struct HeadPlan {
+  bool searched = false, valid = false;
+  int opR = -1, opGa = -1, opGb = -1, opBa = -1, opBb = -1, opCat = -1, opBeta = -1, first = -1;
+  int* d_itab = nullptr;
+  float* d_ftab = nullptr;
+  float* d_comp = nullptr;
+  size_t comp_cap = 0;
+  int halo = 0;
 };
 
 }  // namespace
@@ -141,7 +155,17 @@ struct ian_handle {
   long long run_serial = 0;  // incremented per executed segment (fused head bookkeeping)
   std::vector<float> dec_cache_z;
   std::vector<float> rgb_cache;  // host copy of the brush image last uploaded to d_rgb
+  // NPE.paint photo blend (ian_photo_blend): device copies of RECON / ERROR with their host shadows, outputs
+  unsigned char* d_recon = nullptr;
+  float* d_error = nullptr;
+  unsigned char* d_im = nullptr;
+  double* d_mask = nullptr;
+  std::vector<unsigned char> recon_cache;
+  std::vector<float> error_cache;
+  unsigned char* d_u8 = nullptr;
+  size_t u8_cap = 0;
   bool dec_cache_valid = false;
+  HeadPlan head;
   // profiling
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -874,6 +898,122 @@ int run_mdc_head_group(ian_handle* h, OpPlan& op, int n, hipStream_t st) {
   return 0;
 }
 
+// ----- fused RGB-Beta head (kernels_head.hip) --------------------------------------------------------------------
+bool same_taps(const TgLayer& A, const TgLayer& B) {
+  if (A.taps.size() != B.taps.size() || A.classes.size() != 1 || B.classes.size() != 1) return false;
+  for (size_t t = 0; t < A.taps.size(); ++t)
+    if (A.taps[t].dy != B.taps[t].dy || A.taps[t].dx != B.taps[t].dx) return false;
+  return true;
+}
+
+int find_head_plan(ian_handle* h) {
+  HeadPlan& P = h->head;
+  P.searched = true;
+  const int nops = (int)h->ops.size();
+  std::vector<int> prod(h->slots.size(), -1);
+  for (int i = 0; i < nops; ++i) prod[h->ops[i].d.dst] = i;
+  auto mdc2 = [&](int i) { return i >= 0 && h->ops[i].d.kind == IAN_OP_MDC3 && h->ops[i].d.cout == 2 && h->ops[i].d.segment == IAN_SEG_DEC; };
+  for (int ib = 0; ib < nops; ++ib) {
+    const ian_op_desc& b = h->ops[ib].d;
+    if (b.kind != IAN_OP_BETA || b.dst != h->desc.out_slot || b.src < 0 || b.src2 < 0 || b.src3 < 0) continue;
+    const int iR = prod[b.src], iGb = prod[b.src2], iBb = prod[b.src3];
+    if (!mdc2(iR) || !mdc2(iGb) || !mdc2(iBb)) continue;
+    const ian_op_desc &R = h->ops[iR].d, &Gb = h->ops[iGb].d, &Bb = h->ops[iBb].d;
+    if (R.src2 >= 0 || Gb.src != R.dst || Gb.src2 < 0 || Bb.src2 < 0 || Gb.cin != 2 || Bb.cin != 4) continue;
+    const int iGa = prod[Gb.src2], iBa = prod[Bb.src2], iCat = prod[Bb.src];
+    if (!mdc2(iGa) || !mdc2(iBa) || iCat < 0) continue;
+    const ian_op_desc &Ga = h->ops[iGa].d, &Ba = h->ops[iBa].d, &Cat = h->ops[iCat].d;
+    if (Cat.kind != IAN_OP_CONCAT || Cat.src != R.dst || Cat.src2 != Gb.dst) continue;
+    if (Ga.src != R.src || Ba.src != R.src || Ga.src2 >= 0 || Ba.src2 >= 0) continue;
+    if (R.cin != 128 || R.in_w != 64 || h->slots[R.src].cs != 128) continue;
+    const TgLayer& LR = h->ops[iR].fwd;
+    bool ok = same_taps(LR, h->ops[iGa].fwd) && same_taps(LR, h->ops[iBa].fwd) && same_taps(LR, h->ops[iGb].fwd) &&
+              same_taps(LR, h->ops[iBb].fwd) && LR.taps.size() * 6 <= 224 && LR.taps.size() <= 48;
+    int halo = 0;
+    std::vector<int> per_dy(9, 0);
+    for (auto& t : LR.taps) {
+      if (t.dy < -4 || t.dy > 4 || t.dx < -64 || t.dx > 64) ok = false;
+      else if (++per_dy[t.dy + 4] > 12) ok = false;
+      halo = std::max(halo, std::abs(t.dy));
+    }
+    // each of the three slots must feed nothing but the head (they are never materialised by the fused launch)
+    for (int i = 0; i < nops && ok; ++i) {
+      const ian_op_desc& d = h->ops[i].d;
+      for (int sl : {Ga.dst, Ba.dst, Cat.dst})
+        if ((d.src == sl || d.src2 == sl || d.src3 == sl) && i != iGb && i != iBb) ok = false;
+    }
+    if (!ok) continue;
+    P.opR = iR; P.opGa = iGa; P.opGb = iGb; P.opBa = iBa; P.opBb = iBb; P.opCat = iCat; P.opBeta = ib; P.halo = halo;
+    P.first = std::min({iR, iGa, iBa});
+    // tables: taps grouped by dy (the shift-add of head6_kernel) and the six filters' epilogues
+    std::vector<int> itab(256, 0);
+    for (size_t t = 0; t < LR.taps.size(); ++t) {
+      const int dyi = LR.taps[t].dy + 4;
+      itab[16 + dyi * 12 + itab[dyi]] = (int)t;
+      itab[dyi]++;
+      itab[128 + t] = LR.taps[t].dx;
+    }
+    std::vector<float> ftab(32, 0.f);
+    const int six[3] = {iR, iGa, iBa};
+    for (int k = 0; k < 3; ++k)
+      for (int c = 0; c < 2; ++c) {
+        const OpPlan& o = h->ops[six[k]];
+        ftab[2 * k + c] = o.h_scale.empty() ? 1.f : o.h_scale[c];
+        ftab[8 + 2 * k + c] = o.h_shift.empty() ? 0.f : o.h_shift[c];
+        ftab[16 + 2 * k + c] = (float)o.d.act;
+      }
+    int rc;
+    if ((rc = upload(h, itab, &P.d_itab))) return rc;
+    if ((rc = upload(h, ftab, &P.d_ftab))) return rc;
+    P.valid = true;
+    return 0;
+  }
+  return 0;
+}
+
+bool head_fused_active(const ian_handle* h, int n) {
+  return h->head.valid && h->opt.head_fused && h->opt.mdc_head && n >= h->opt.head_fused_min_n;
+}
+
+int run_head_fused(ian_handle* h, int n, hipStream_t st) {
+  HeadPlan& P = h->head;
+  const OpPlan &R = h->ops[P.opR], &Ga = h->ops[P.opGa], &Gb = h->ops[P.opGb], &Ba = h->ops[P.opBa], &Bb = h->ops[P.opBb];
+  const Slot& src = h->slots[R.d.src];
+  const int H = R.d.in_h, W = R.d.in_w;
+  const size_t need = (size_t)n * H * W * 8;
+  if (need > P.comp_cap) {
+    if (P.d_comp) HIPCHK(h, hipFree(P.d_comp));
+    HIPCHK(h, hipMalloc((void**)&P.d_comp, need * sizeof(float)));
+    P.comp_cap = need;
+  }
+  int rc;
+  if ((rc = ensure_slot(h, h->desc.out_slot, n))) return rc;
+  HeadFusedArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = src.d; a.w0 = R.fwd.d_w; a.w1 = Ga.fwd.d_w; a.w2 = Ba.fwd.d_w; a.out = P.d_comp; a.itab = P.d_itab; a.ftab = P.d_ftab;
+  a.H = H; a.W = W; a.xs = src.cs; a.ntaps = (int)R.fwd.taps.size(); a.halo = P.halo;
+  a.w_tap_stride = (long long)R.fwd.CoutPad * R.fwd.Cin;
+  // bands: whole images per workgroup when the batch alone fills the chip (no halo rows recomputed); smaller batches
+  // are cut into row bands so that at least ~256 workgroups exist (each band re-reads 2*halo rows)
+  int bands = 1;
+  while (n * bands < 256 && bands < 8 && (H % (bands * 2)) == 0 && H / (bands * 2) >= 2 * P.halo) bands *= 2;
+  a.bands = bands;
+  HIPCHK(h, launch_head6(a, n, st));
+  HeadTailArgs t;
+  memset(&t, 0, sizeof t);
+  t.comp = P.d_comp; t.w_gb = Gb.fwd.d_w; t.w_bb = Bb.fwd.d_w; t.out = h->slots[h->desc.out_slot].d;
+  t.gb_tap_stride = (long long)Gb.fwd.CoutPad * Gb.fwd.Cin; t.bb_tap_stride = (long long)Bb.fwd.CoutPad * Bb.fwd.Cin;
+  t.gb_cin = Gb.fwd.Cin; t.bb_cin = Bb.fwd.Cin;
+  for (int c = 0; c < 2; ++c) {
+    t.scale_g[c] = Gb.h_scale.empty() ? 1.f : Gb.h_scale[c]; t.shift_g[c] = Gb.h_shift.empty() ? 0.f : Gb.h_shift[c];
+    t.scale_b[c] = Bb.h_scale.empty() ? 1.f : Bb.h_scale[c]; t.shift_b[c] = Bb.h_shift.empty() ? 0.f : Bb.h_shift[c];
+  }
+  t.act_g = Gb.d.act; t.act_b = Bb.d.act; t.H = H; t.W = W; t.ntaps = a.ntaps;
+  for (int k = 0; k < a.ntaps; ++k) { t.dy[k] = (signed char)R.fwd.taps[k].dy; t.dx[k] = (signed char)R.fwd.taps[k].dx; }
+  HIPCHK(h, launch_head_tail(t, n, st));
+  return 0;
+}
+
 TgEpilogue fwd_epi(const OpPlan& op, const float* res) {
   TgEpilogue e;
   e.scale = op.d_scale; e.shift = op.d_shift; e.res = res; e.yfwd = nullptr; e.act = op.d.act; e.mode = TG_EPI_FWD;
@@ -937,11 +1077,21 @@ int run_op_fwd(ian_handle* h, OpPlan& op, int n, hipStream_t st) {
 
 int run_segment(ian_handle* h, int seg, int n, hipStream_t st) {
   ++h->run_serial;
-  for (auto& op : h->ops)
-    if (op.d.segment == seg) {
-      int rc = run_op_fwd(h, op, n, st);
-      if (rc) return rc;
+  const bool fused = seg == IAN_SEG_DEC && head_fused_active(h, n);
+  const HeadPlan& P = h->head;
+  for (int i = 0; i < (int)h->ops.size(); ++i) {
+    OpPlan& op = h->ops[i];
+    if (op.d.segment != seg) continue;
+    if (fused && (i == P.opR || i == P.opGa || i == P.opGb || i == P.opBa || i == P.opBb || i == P.opCat || i == P.opBeta)) {
+      if (i == P.first) {   // the 128-channel map all of them hang off is ready: the whole head in two launches
+        int rc = run_head_fused(h, n, st);
+        if (rc) return rc;
+      }
+      continue;
     }
+    int rc = run_op_fwd(h, op, n, st);
+    if (rc) return rc;
+  }
   return 0;
 }
 
@@ -1272,12 +1422,10 @@ int run_decoder_backward(ian_handle* h, int mode, int c1, int r1, int c2, int r2
   return 0;
 }
 
-int grad_common(ian_handle* h, int mode, int c1, int r1, int c2, int r2, const float* rgb, const float* z, float* dz,
-                void* stream) {
-  int rc = check_ready(h, 1);
-  if (rc) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  TotalTimer tt(h, st);
+// batch-1 decoder forward for latent z unless the resident activations already belong to it (NPE.py:205,218:
+// imgradRGB(z) right after sample_at(z), the blend right after the brush step)
+int decode_one_cached(ian_handle* h, const float* z, hipStream_t st) {
+  int rc;
   const bool host_z = !is_device_ptr(z);
   const bool hit = h->dec_cache_valid && host_z && getenv("IAN_NO_DEC_CACHE") == nullptr &&
                    memcmp(h->dec_cache_z.data(), z, sizeof(float) * h->desc.num_latents) == 0;
@@ -1290,6 +1438,16 @@ int grad_common(ian_handle* h, int mode, int c1, int r1, int c2, int r2, const f
       h->dec_cache_valid = true;
     }
   }
+  return 0;
+}
+
+int grad_common(ian_handle* h, int mode, int c1, int r1, int c2, int r2, const float* rgb, const float* z, float* dz,
+                void* stream) {
+  int rc = check_ready(h, 1);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  TotalTimer tt(h, st);
+  if ((rc = decode_one_cached(h, z, st))) return rc;
   const float* d_rgb = nullptr;
   if (mode == 1) {
     Slot& out = h->slots[h->desc.out_slot];
@@ -1436,7 +1594,7 @@ int ian_finalize(ian_handle* h) {
   }
   h->params.clear();
   h->finalized = true;
-  return 0;
+  return find_head_plan(h);
 }
 
 int ian_encode_pre_iaf(ian_handle* h, const float* x, int32_t n, float* z, void* stream) {
@@ -1498,6 +1656,83 @@ int ian_reconstruct(ian_handle* h, const float* x, int32_t n, float* xhat, void*
   if ((rc = run_segment(h, IAN_SEG_IAF, n, st))) return rc;
   if ((rc = run_segment(h, IAN_SEG_DEC, n, st))) return rc;
   return get_image_output(h, xhat, n, st);
+}
+
+int ian_decode_u8(ian_handle* h, const float* z, int32_t n, uint8_t* out, void* stream) {
+  int rc = check_ready(h, n);
+  if (rc) return rc;
+  if (!z || !out) return fail(h, -1, "null pointer passed to ian_decode_u8");
+  hipStream_t st = (hipStream_t)stream;
+  TotalTimer tt(h, st);
+  if (n == 1) {
+    if ((rc = decode_one_cached(h, z, st))) return rc;
+  } else {
+    h->dec_cache_valid = false;
+    if ((rc = set_latent_input(h, h->desc.z_slot, z, n, st))) return rc;
+    if ((rc = run_segment(h, IAN_SEG_DEC, n, st))) return rc;
+  }
+  Slot& os = h->slots[h->desc.out_slot];
+  const size_t count = os.per_image() * (size_t)n;
+  if (is_device_ptr(out)) {
+    HIPCHK(h, launch_to_uint8(os.d, out, (long long)count, st));
+    return 0;
+  }
+  if (count > h->u8_cap) {
+    if (h->d_u8) HIPCHK(h, hipFree(h->d_u8));
+    HIPCHK(h, hipMalloc((void**)&h->d_u8, count));
+    h->u8_cap = count;
+  }
+  HIPCHK(h, launch_to_uint8(os.d, h->d_u8, (long long)count, st));
+  HIPCHK(h, hipMemcpyAsync(out, h->d_u8, count, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  return 0;
+}
+
+int ian_photo_blend(ian_handle* h, const float* z, const uint8_t* recon, const float* error, const double* gauss_half,
+                    int32_t radius, uint8_t* im, double* mask, void* stream) {
+  int rc = check_ready(h, 1);
+  if (rc) return rc;
+  if (!z || !recon || !error || !gauss_half || !im) return fail(h, -1, "null pointer passed to ian_photo_blend");
+  if (radius < 0 || radius > 7) return fail(h, -7, "ian_photo_blend: radius %d outside 0..7", radius);
+  Slot& os = h->slots[h->desc.out_slot];
+  if (os.h != 64 || os.w != 64 || os.c != 3) return fail(h, -7, "ian_photo_blend needs a 3x64x64 image");
+  hipStream_t st = (hipStream_t)stream;
+  TotalTimer tt(h, st);
+  if ((rc = decode_one_cached(h, z, st))) return rc;
+  const size_t cnt = 3 * 64 * 64;
+  PhotoBlendArgs a;
+  memset(&a, 0, sizeof a);
+  a.xhat = os.d;
+  if (is_device_ptr(recon)) a.recon = recon;
+  else {
+    if (!h->d_recon) HIPCHK(h, hipMalloc((void**)&h->d_recon, cnt));
+    if (h->recon_cache.size() != cnt || memcmp(h->recon_cache.data(), recon, cnt) != 0) {   // changes on infer / Reset only
+      HIPCHK(h, hipMemcpyAsync(h->d_recon, recon, cnt, hipMemcpyHostToDevice, st));
+      h->recon_cache.assign(recon, recon + cnt);
+    }
+    a.recon = h->d_recon;
+  }
+  if (is_device_ptr(error)) a.error = error;
+  else {
+    if (!h->d_error) HIPCHK(h, hipMalloc((void**)&h->d_error, cnt * sizeof(float)));
+    if (h->error_cache.size() != cnt || memcmp(h->error_cache.data(), error, cnt * sizeof(float)) != 0) {
+      HIPCHK(h, hipMemcpyAsync(h->d_error, error, cnt * sizeof(float), hipMemcpyHostToDevice, st));
+      h->error_cache.assign(error, error + cnt);
+    }
+    a.error = h->d_error;
+  }
+  const bool im_dev = is_device_ptr(im), mask_dev = mask && is_device_ptr(mask);
+  if (!im_dev && !h->d_im) HIPCHK(h, hipMalloc((void**)&h->d_im, cnt));
+  if (mask && !mask_dev && !h->d_mask) HIPCHK(h, hipMalloc((void**)&h->d_mask, 64 * 64 * sizeof(double)));
+  a.im = im_dev ? im : h->d_im;
+  a.mask = mask ? (mask_dev ? mask : h->d_mask) : nullptr;
+  for (int i = 0; i <= radius; ++i) a.w[i] = gauss_half[i];
+  a.radius = radius;
+  HIPCHK(h, launch_photo_blend(a, st));
+  if (!im_dev) HIPCHK(h, hipMemcpyAsync(im, h->d_im, cnt, hipMemcpyDeviceToHost, st));
+  if (mask && !mask_dev) HIPCHK(h, hipMemcpyAsync(mask, h->d_mask, 64 * 64 * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (!im_dev || (mask && !mask_dev)) HIPCHK(h, hipStreamSynchronize(st));
+  return 0;
 }
 
 int ian_autotune(ian_handle* h, int32_t n, int32_t what, void* stream) {
@@ -1673,6 +1908,8 @@ int ian_set_option(ian_handle* h, const char* key, int32_t value) {
   else if (k == "tg_nosplit_min_out") h->opt.tg_nosplit_min_out = value;
   else if (k == "tg_variant") h->opt.tg_variant = value;
   else if (k == "mdc_head") h->opt.mdc_head = value;
+  else if (k == "head_fused") h->opt.head_fused = value;
+  else if (k == "head_fused_min_n") h->opt.head_fused_min_n = std::max(1, value);
   else return fail(h, -1, "unknown option '%s'", key);
   for (auto& op : h->ops) {  // schedules depend on the options
     free_schedules(op.fwd);
@@ -1698,7 +1935,10 @@ void ian_destroy(ian_handle* h) {
     if (s.d) (void)hipFree(s.d);
     if (s.g) (void)hipFree(s.g);
   }
-  for (float* p : {h->d_slab, h->d_stage_in, h->d_stage_out, h->d_gseed, h->d_rgb})
+  for (float* p : {h->d_slab, h->d_stage_in, h->d_stage_out, h->d_gseed, h->d_rgb, h->head.d_ftab, h->head.d_comp})
+    if (p) (void)hipFree(p);
+  if (h->head.d_itab) (void)hipFree(h->head.d_itab);
+  for (void* p : {(void*)h->d_recon, (void*)h->d_error, (void*)h->d_im, (void*)h->d_mask, (void*)h->d_u8})
     if (p) (void)hipFree(p);
   for (auto& e : h->ev_pool) {
     (void)hipEventDestroy(e.first);

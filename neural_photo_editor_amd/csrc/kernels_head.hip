@@ -1,0 +1,293 @@
+// RGB-Beta head of the full IAN in two launches (IAN.py:183-207; layers.py:207-258 MDCL, 397-408 beta_layer).
+//
+//   R = sigmoid(MDCL_R(h))            G = sigmoid(MDCL_Ga(h) + MDCL_Gb(R))          B = sigmoid(MDCL_Ba(h) + MDCL_Bb([R,G]))
+//   out_c = 2a/(a+b+1e-8) - 1  for (a,b) = the two channels of R, G, B           h: (n,128,64,64), every MDCL 2 filters, scales [2,3,4]
+//
+// Round 1 ran this as 5 launches over 32-channel-padded 2-channel maps (3.27 ms of the 18.7 ms full-IAN step at batch 256,
+// h read 2.8x).  The three filters pairs that read h (R, G_a, B_a: 6 filters x 33 taps x 128 channels = 98 % of the head's
+// arithmetic) are the problem: 6 output channels waste an MFMA tile, and as FMA work they ran at 16 % of the VALU peak.
+//
+// head6_kernel: "contract first, shift later".  out[p][f] = sum_t sum_c h[p+d_t][c] * W[t][f][c] is evaluated as
+//       Y[q][(t,f)] = sum_c h[q][c] * W[t][f][c]              -- ONE dense 128 -> 198 contraction per input pixel: fp32 MFMA,
+//                                                                N = 33 taps x 6 filters = 198 of 224 tile columns used
+//       out[p][f]   = sum_t Y[p + d_t][(t,f)]                 -- 33 shifted adds per output value, on the VALU, through LDS
+//   so h is read from HBM exactly once (no halo when a workgroup owns whole image rows), the weights sit in registers
+//   (128 VGPRs per lane for the whole kernel) and the matrix cores see a well-shaped 64 x 224 x 128 tile per image row.
+//   A workgroup walks the input rows of its band in order; Y of one row lives in LDS; an output row is open while the
+//   input rows y-4..y+4 pass by (ring of 16 rows x 64 x 6 accumulators in LDS) -- contributions are added by fixed owner
+//   threads in a fixed order, so results are bitwise reproducible (no atomics).  Result: a compact [n][H][W][8] map
+//   (R after its sigmoid, G_a and B_a raw), 32 B per pixel instead of 3 x 128 B.
+// head_tail_kernel: one workgroup per image keeps the compact map in LDS (96 KB) and runs G_b (2->2), B_b (4->2), the
+//   sigmoids and the three beta_layers, writing the NCHW image.  ~1.6 M MAC per image: LDS-resident VALU work.
+#include "ian_internal.h"
+
+namespace ian {
+
+typedef float hd_f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float hd_act(float v, int act) {
+  switch (act) {
+    case 1: return v > 0.f ? v : 0.f;
+    case 2: return v > 0.f ? v : 0.2f * v;
+    case 3: return v > 0.f ? v : expm1f(v);
+    case 4: return tanhf(v);
+    case 5: return 1.f / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+
+constexpr int HD_W = 64;          // image width (pixels per row = M of the per-row GEMM)
+constexpr int HD_CIN = 128;       // input channels (K)
+constexpr int HD_XS = HD_CIN + 4; // LDS row stride of the staged input row: ds_read_b128 conflict-free (132*4 B = 16 mod 256)
+constexpr int HD_NF = 6;          // fused filters
+constexpr int HD_YS = 230;        // LDS row stride of Y: >= 224 and = 6 mod 32 -> the shift-add reads are conflict-free
+constexpr int HD_RING = 16;       // open output rows (power of two >= 9)
+
+template <int NTILES>  // N tiles of 32 columns actually holding (tap,filter) pairs: ceil(ntaps*6/32) <= 7
+__global__ __launch_bounds__(512, 2) void head6_kernel(HeadFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Xs = sm;                                   // [2][64][132]
+  float* Ys = Xs + 2 * HD_W * HD_XS;                // [64][230]
+  float* ring = Ys + HD_W * HD_YS;                  // [16][64][6]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wg = wave >> 1;          // M tile (32 pixels), N group
+  const int band = blockIdx.x % a.bands, img = blockIdx.x / a.bands;
+  const int rows_per_band = a.H / a.bands;
+  const int y0 = band * rows_per_band, y1 = y0 + rows_per_band;
+  const int r_begin = max(0, y0 - a.halo), r_end = min(a.H, y1 + a.halo);
+  const int N = a.ntaps * HD_NF;
+
+  // ---- weights -> registers.  MFMA B operand of step (kk, c): lane l holds W[j = 32*nt + (l&31)][k = 8*kk + 4*(l>>5) + c]
+  float wreg[2][64];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int nt = wg + 4 * i;
+    const int j = nt * 32 + (lane & 31);
+    const bool ok = (nt < NTILES) && (j < N);
+    const int t = ok ? j / HD_NF : 0, f = ok ? j % HD_NF : 0;
+    const float* wbase = (f >> 1) == 0 ? a.w0 : ((f >> 1) == 1 ? a.w1 : a.w2);
+    const float* wp = wbase + (long long)t * a.w_tap_stride + (f & 1) * HD_CIN + (lane >> 5) * 4;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4*>(wp + kk * 8);
+      wreg[i][kk * 4 + 0] = v.x; wreg[i][kk * 4 + 1] = v.y; wreg[i][kk * 4 + 2] = v.z; wreg[i][kk * 4 + 3] = v.w;
+    }
+  }
+  for (int i = tid; i < HD_RING * HD_W * HD_NF; i += 512) ring[i] = 0.f;
+
+  // ---- staging of one input row: 64 pixels x 128 channels = 2048 float4, 4 per thread, fully coalesced
+  const float* xin = a.x + (size_t)img * a.H * HD_W * a.xs;
+  float4 st0, st1, st2, st3;  // named registers (an indexed array captured by a lambda ended up in scratch)
+  const int s_px = tid >> 5, s_c4 = (tid & 31) * 4;   // element e = tid + 512*q -> pixel s_px + 16*q, channel quad s_c4
+#define HD_LOAD_ROW(r)                                                                                      \
+  {                                                                                                        \
+    const float* rp_ = xin + ((size_t)(r) * HD_W + s_px) * a.xs + s_c4;                                     \
+    st0 = *reinterpret_cast<const float4*>(rp_);                                                           \
+    st1 = *reinterpret_cast<const float4*>(rp_ + (size_t)16 * a.xs);                                       \
+    st2 = *reinterpret_cast<const float4*>(rp_ + (size_t)32 * a.xs);                                       \
+    st3 = *reinterpret_cast<const float4*>(rp_ + (size_t)48 * a.xs);                                       \
+  }
+#define HD_STORE_ROW(buf)                                                                                   \
+  {                                                                                                        \
+    float* sp_ = Xs + ((buf) * HD_W + s_px) * HD_XS + s_c4;                                                 \
+    *reinterpret_cast<float4*>(sp_) = st0;                                                                 \
+    *reinterpret_cast<float4*>(sp_ + 16 * HD_XS) = st1;                                                    \
+    *reinterpret_cast<float4*>(sp_ + 32 * HD_XS) = st2;                                                    \
+    *reinterpret_cast<float4*>(sp_ + 48 * HD_XS) = st3;                                                    \
+  }
+  HD_LOAD_ROW(r_begin);
+  HD_STORE_ROW(0);
+  __syncthreads();
+
+  const float* a_base = Xs + (wm * 32 + (lane & 31)) * HD_XS + (lane >> 5) * 4;
+  const int col_l = lane & 31, rhalf = 4 * (lane >> 5);
+  float* out = a.out + (size_t)img * a.H * HD_W * 8;
+
+  for (int r = r_begin; r < r_end; ++r) {
+    const int buf = (r - r_begin) & 1;
+    if (r + 1 < r_end) HD_LOAD_ROW(r + 1);   // in flight during the MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- Y tile(s) of this wave: 32 pixels x 32 columns each, K = 128
+    hd_f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const float* ap = a_base + buf * HD_W * HD_XS;
+    const bool two = (wg + 4) < NTILES;  // wave-uniform
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float4 av = *reinterpret_cast<const float4*>(ap + kk * 8);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wreg[0][kk * 4 + 0], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wreg[0][kk * 4 + 1], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wreg[0][kk * 4 + 2], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wreg[0][kk * 4 + 3], acc[0], 0, 0, 0);
+      if (two) {
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wreg[1][kk * 4 + 0], acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wreg[1][kk * 4 + 1], acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wreg[1][kk * 4 + 2], acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wreg[1][kk * 4 + 3], acc[1], 0, 0, 0);
+      }
+    }
+    // ---- Y -> LDS.  C layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i == 1 && !two) break;
+      const int jcol = (wg + 4 * i) * 32 + col_l;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int px = wm * 32 + (e & 3) + 8 * (e >> 2) + rhalf;
+        Ys[px * HD_YS + jcol] = acc[i][e];
+      }
+    }
+    if (r + 1 < r_end) HD_STORE_ROW(buf ^ 1);  // the other buffer: nobody reads it during this row
+    __syncthreads();
+    // ---- shift-add: out[y = r - dy][x][f] += sum over the taps with that dy of Y[x + dx][(t,f)]
+    for (int it = tid; it < 9 * HD_W * HD_NF; it += 512) {
+      const int f = it % HD_NF, x = (it / HD_NF) % HD_W, dyi = it / (HD_W * HD_NF);
+      const int y = r - (dyi - 4);
+      if (y < y0 || y >= y1) continue;
+      float s = 0.f;
+      const int nt = a.itab[dyi];
+      for (int q = 0; q < nt; ++q) {
+        const int t = a.itab[16 + dyi * 12 + q];
+        const int xx = x + a.itab[128 + t];
+        if ((unsigned)xx < (unsigned)HD_W) s += Ys[xx * HD_YS + t * HD_NF + f];
+      }
+      ring[((y & (HD_RING - 1)) * HD_W + x) * HD_NF + f] += s;
+    }
+    __syncthreads();
+    // ---- output rows no later input row can reach are complete: y = r - halo, and everything still open after the
+    // image's last row
+    {
+      const int lo = max(y0, r - a.halo), hi = min(y1 - 1, (r == a.H - 1) ? y1 - 1 : r - a.halo);
+      for (int yf = lo; yf <= hi; ++yf) {
+        if (tid < HD_W * HD_NF) {
+          const int f = tid % HD_NF, x = tid / HD_NF;
+          float* rp = ring + ((yf & (HD_RING - 1)) * HD_W + x) * HD_NF + f;
+          const float v = hd_act(*rp * a.ftab[f] + a.ftab[8 + f], (int)a.ftab[16 + f]);
+          out[((size_t)yf * HD_W + x) * 8 + f] = v;
+          *rp = 0.f;
+        }
+      }
+    }
+    __syncthreads();  // the resets above are made by other threads than the next row's adds
+  }
+}
+
+#undef HD_LOAD_ROW
+#undef HD_STORE_ROW
+
+hipError_t launch_head6(const HeadFusedArgs& a, int n, hipStream_t s) {
+  if (a.W != HD_W || a.ntaps * HD_NF > 224 || a.bands < 1 || (a.H % a.bands) || a.halo > 4 || a.xs < HD_CIN) return hipErrorInvalidValue;
+  const size_t lds = (size_t)(2 * HD_W * HD_XS + HD_W * HD_YS + HD_RING * HD_W * HD_NF) * sizeof(float);
+  const int ntiles = (a.ntaps * HD_NF + 31) / 32;
+#define HD_LAUNCH(NT)                                                                                             \
+  {                                                                                                               \
+    static bool attr = false;                                                                                     \
+    auto k = head6_kernel<NT>;                                                                                    \
+    if (!attr) {                                                                                                  \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return e;                                                                              \
+      attr = true;                                                                                                \
+    }                                                                                                             \
+    hipLaunchKernelGGL(k, dim3(n * a.bands), dim3(512), lds, s, a);                                               \
+    return hipGetLastError();                                                                                     \
+  }
+  if (ntiles <= 4) HD_LAUNCH(4)
+  if (ntiles <= 6) HD_LAUNCH(6)
+  HD_LAUNCH(7)
+#undef HD_LAUNCH
+}
+
+// ------------------------------------------------------------------------------------------------
+// head_tail_kernel: G = act_g((Ga + MDCL_Gb(R))*s+b), B = act_b((Ba + MDCL_Bb([R,G]))*s+b), beta x3 -> NCHW.  One workgroup
+// (1024 threads) per image; the compact map of head6_kernel sits in LDS as [pixel][6] = (R0,R1,Ga0|G0,Ga1|G1,Ba0,Ba1).
+// ------------------------------------------------------------------------------------------------
+constexpr int HT_T = 1024;
+__global__ __launch_bounds__(HT_T) void head_tail_kernel(HeadTailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int HW = a.H * a.W;
+  float* m = sm;                       // [HW][6]
+  float* wg = m + HW * 6;              // [ntaps][2 out][2 in]
+  float* wb = wg + a.ntaps * 4;        // [ntaps][2 out][4 in]
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const float* src = a.comp + (size_t)img * HW * 8;
+  for (int i = tid; i < HW * 2; i += HT_T) {   // 2 float4 per pixel -> 6 floats kept
+    const int p = i >> 1, hlf = i & 1;
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)p * 8 + hlf * 4);
+    if (hlf == 0) { m[p * 6 + 0] = v.x; m[p * 6 + 1] = v.y; m[p * 6 + 2] = v.z; m[p * 6 + 3] = v.w; }
+    else { m[p * 6 + 4] = v.x; m[p * 6 + 5] = v.y; }
+  }
+  for (int i = tid; i < a.ntaps * 4; i += HT_T) {
+    const int t = i >> 2, co = (i >> 1) & 1, ci = i & 1;
+    wg[i] = a.w_gb[(long long)t * a.gb_tap_stride + co * a.gb_cin + ci];
+  }
+  for (int i = tid; i < a.ntaps * 8; i += HT_T) {
+    const int t = i >> 3, co = (i >> 2) & 1, ci = i & 3;
+    wb[i] = a.w_bb[(long long)t * a.bb_tap_stride + co * a.bb_cin + ci];
+  }
+  __syncthreads();
+  // ---- G: reads R of the neighbourhood, its own Ga; written in place of Ga after everyone has read... Ga is only read by
+  // its own pixel, so in-place is safe without a second buffer
+  for (int p = tid; p < HW; p += HT_T) {
+    const int py = p / a.W, px = p % a.W;
+    float s0 = 0.f, s1 = 0.f;
+    for (int t = 0; t < a.ntaps; ++t) {
+      const int yy = py + a.dy[t], xx = px + a.dx[t];
+      if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) {
+        const float2 r = *reinterpret_cast<const float2*>(m + (yy * a.W + xx) * 6);
+        const float4 w = *reinterpret_cast<const float4*>(wg + t * 4);
+        s0 = fmaf(r.x, w.x, s0); s0 = fmaf(r.y, w.y, s0);
+        s1 = fmaf(r.x, w.z, s1); s1 = fmaf(r.y, w.w, s1);
+      }
+    }
+    const float g0 = hd_act((s0 + m[p * 6 + 2]) * a.scale_g[0] + a.shift_g[0], a.act_g);
+    const float g1 = hd_act((s1 + m[p * 6 + 3]) * a.scale_g[1] + a.shift_g[1], a.act_g);
+    m[p * 6 + 2] = g0;
+    m[p * 6 + 3] = g1;
+  }
+  __syncthreads();
+  float* outp = a.out + (size_t)img * 3 * HW;
+  for (int p = tid; p < HW; p += HT_T) {
+    const int py = p / a.W, px = p % a.W;
+    float s0 = 0.f, s1 = 0.f;
+    for (int t = 0; t < a.ntaps; ++t) {
+      const int yy = py + a.dy[t], xx = px + a.dx[t];
+      if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) {
+        const float* q = m + (yy * a.W + xx) * 6;   // (R0,R1,G0,G1) = the ConcatLayer([R,G]) channel order (IAN.py:201)
+        const float2 r = *reinterpret_cast<const float2*>(q);
+        const float2 g = *reinterpret_cast<const float2*>(q + 2);
+        const float4 w0 = *reinterpret_cast<const float4*>(wb + t * 8), w1 = *reinterpret_cast<const float4*>(wb + t * 8 + 4);
+        s0 = fmaf(r.x, w0.x, s0); s0 = fmaf(r.y, w0.y, s0); s0 = fmaf(g.x, w0.z, s0); s0 = fmaf(g.y, w0.w, s0);
+        s1 = fmaf(r.x, w1.x, s1); s1 = fmaf(r.y, w1.y, s1); s1 = fmaf(g.x, w1.z, s1); s1 = fmaf(g.y, w1.w, s1);
+      }
+    }
+    const float b0 = hd_act((s0 + m[p * 6 + 4]) * a.scale_b[0] + a.shift_b[0], a.act_b);
+    const float b1 = hd_act((s1 + m[p * 6 + 5]) * a.scale_b[1] + a.shift_b[1], a.act_b);
+    const float r0 = m[p * 6 + 0], r1 = m[p * 6 + 1], g0 = m[p * 6 + 2], g1 = m[p * 6 + 3];
+    // beta_layer (layers.py:397-408): 2*(alpha/(alpha+beta+1e-8)) - 1
+    outp[p] = 2.f * (r0 / (r0 + r1 + 1e-8f)) - 1.f;
+    outp[HW + p] = 2.f * (g0 / (g0 + g1 + 1e-8f)) - 1.f;
+    outp[2 * HW + p] = 2.f * (b0 / (b0 + b1 + 1e-8f)) - 1.f;
+  }
+}
+
+hipError_t launch_head_tail(const HeadTailArgs& a, int n, hipStream_t s) {
+  if (a.ntaps > 48 || a.H * a.W > 4096) return hipErrorInvalidValue;
+  const size_t lds = (size_t)(a.H * a.W * 6 + a.ntaps * 12) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)((4096 * 6 + 48 * 12) * sizeof(float)));
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(head_tail_kernel, dim3(n), dim3(HT_T), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace ian

@@ -41,7 +41,8 @@ class ModelDesc(C.Structure):
 
 EXPORTS = (
     "ian_create", "ian_load_param", "ian_set_made_masks", "ian_finalize", "ian_encode", "ian_decode",
-    "ian_encode_pre_iaf", "ian_iaf", "ian_reconstruct", "ian_grad_rgb", "ian_grad_light", "ian_read_slot", "ian_read_slot_grad",
+    "ian_encode_pre_iaf", "ian_iaf", "ian_reconstruct", "ian_grad_rgb", "ian_grad_light", "ian_decode_u8", "ian_photo_blend",
+    "ian_read_slot", "ian_read_slot_grad",
     "ian_profile_enable", "ian_profile_read", "ian_autotune", "ian_set_option", "ian_last_error", "ian_version", "ian_destroy",
 )
 
@@ -75,6 +76,8 @@ def load_library():
         getattr(lib, fn).argtypes = [vp, fp, i32, fp, vp]
     lib.ian_grad_rgb.argtypes = [vp, i32, i32, i32, i32, fp, fp, fp, vp]
     lib.ian_grad_light.argtypes = [vp, i32, i32, i32, i32, fp, fp, vp]
+    lib.ian_decode_u8.argtypes = [vp, fp, i32, fp, vp]
+    lib.ian_photo_blend.argtypes = [vp, fp, fp, fp, fp, i32, fp, fp, vp]
     lib.ian_read_slot.argtypes = [vp, i32, i32, fp, vp]
     lib.ian_read_slot_grad.argtypes = [vp, i32, i32, fp, vp]
     lib.ian_profile_enable.argtypes = [vp, i32]
@@ -171,6 +174,10 @@ class Handle:
 
     def grad_light(self, c1, r1, c2, r2, z, dz, stream=None):
         self._check(self.lib.ian_grad_light(self._h, c1, r1, c2, r2, _ptr(z), _ptr(dz), C.c_void_p(stream or 0)))
+
+    def photo_blend(self, z, recon_u8, error, gauss_half, im, mask=None, stream=None):
+        self._check(self.lib.ian_photo_blend(self._h, _ptr(z), _ptr(recon_u8), _ptr(error), _ptr(gauss_half), len(gauss_half) - 1,
+                                             _ptr(im), _ptr(mask) if mask is not None else C.c_void_p(0), C.c_void_p(stream or 0)))
 
     def read_slot(self, slot, n):
         h, w, c = self.lowered.slots[slot]

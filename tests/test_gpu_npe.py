@@ -1,0 +1,86 @@
+"""NPE.paint's photo blend (NPE.py:218-231) and the uint8 image conversion (NPE.py:110,261) on the device, against the
+reference's numpy/scipy expression (neural_photo_editor_amd.npe_ops.photo_blend_host): byte work -> bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ian_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "neural_photo_editor_amd", "configs")
+
+
+@pytest.fixture(scope="module")
+def model():
+    from neural_photo_editor_amd import IAN
+    P = O.make_params("IAN_simple", 1)
+    return IAN(os.path.join(CFG, "IAN_simple.py"), True, params=P)
+
+
+def session(model, seed):
+    """What NPE.infer leaves behind (NPE.py:239-274): IM, Z, RECON (uint8), ERROR (float32)."""
+    from neural_photo_editor_amd import npe_ops as N
+    rs = np.random.RandomState(seed)
+    IM = np.uint8((O.make_images(1, seed=seed)[0] + 1.0) * 127.5)
+    Z = model.encode_images(np.asarray([N.to_tanh(IM)], dtype=np.float32))
+    RECON = np.uint8(N.from_tanh(model.sample_at(np.float32(Z))[0]))
+    ERROR = N.to_tanh(np.float32(IM)) - N.to_tanh(np.float32(RECON))
+    return IM, Z + 0.3 * rs.randn(*Z.shape).astype(np.float32), RECON, ERROR
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_photo_blend_is_bit_exact(model, seed):
+    from neural_photo_editor_amd import npe_ops as N
+    IM, Z, RECON, ERROR = session(model, seed)
+    assert ERROR.dtype == np.float32 and RECON.dtype == np.uint8
+    xhat = model.sample_at(Z)[0]
+    want_im, want_mask = N.photo_blend_host(xhat, RECON, ERROR)
+    im, mask = model.photo_blend(Z, RECON, ERROR)
+    assert im.dtype == np.uint8 and mask.dtype == np.float64
+    assert np.array_equal(mask, want_mask)          # float64, bit for bit (scipy's summation order)
+    assert np.array_equal(im, want_im)
+    im2, _ = N.photo_blend(model, Z.reshape(10, 10), RECON, ERROR)       # the NPE-style entry (10x10 latent grid)
+    assert np.array_equal(im2, want_im)
+    assert want_mask.max() > 1e-3 and (im != RECON).any()                # a non-trivial edit
+
+
+def test_photo_blend_out_of_range_wraps_like_numpy(model):
+    """ERROR large enough to push values outside [0,255]: the reference's bare np.uint8 cast wraps; so does the kernel."""
+    from neural_photo_editor_amd import npe_ops as N
+    IM, Z, RECON, ERROR = session(model, 5)
+    ERROR = (ERROR * 6.0).astype(np.float32)
+    xhat = model.sample_at(Z)[0]
+    want_im, want_mask = N.photo_blend_host(xhat, RECON, ERROR)
+    with np.errstate(invalid="ignore"):
+        v = N.from_tanh(N.to_tanh(RECON) + want_mask * (xhat - N.to_tanh(np.float32(RECON))) + (1 - want_mask) * ERROR)
+    assert (v < 0).any() or (v >= 256).any()
+    im, mask = model.photo_blend(Z, RECON, ERROR)
+    assert np.array_equal(im, want_im) and np.array_equal(mask, want_mask)
+
+
+def test_photo_blend_device_pointers(model):
+    import torch
+    from neural_photo_editor_amd import npe_ops as N
+    IM, Z, RECON, ERROR = session(model, 7)
+    want_im, want_mask = model.photo_blend(Z, RECON, ERROR)
+    half = N.gaussian_half_kernel()
+    zd, rd, ed = torch.from_numpy(Z).cuda(), torch.from_numpy(RECON).cuda(), torch.from_numpy(ERROR).cuda()
+    imd, md = torch.zeros(3, 64, 64, dtype=torch.uint8, device="cuda"), torch.zeros(64, 64, dtype=torch.float64, device="cuda")
+    model.handle.photo_blend(zd, rd, ed, half, imd, md, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(imd.cpu().numpy(), want_im) and np.array_equal(md.cpu().numpy(), want_mask)
+
+
+@pytest.mark.parametrize("arch,n", [("IAN_simple", 1), ("IAN_simple", 5), ("IAN", 9)])
+def test_sample_at_uint8(arch, n):
+    """np.uint8(from_tanh(sample_at(z))) (NPE.py:110,261) computed on the device == the host expression, byte for byte."""
+    from neural_photo_editor_amd import IAN, npe_ops as N
+    m = IAN(os.path.join(CFG, arch + ".py"), True, params=O.make_params(arch, 1))
+    z = O.make_latents(n, seed=3) * 2.0
+    want = np.uint8(N.from_tanh(m.sample_at(z)))
+    got = m.sample_at_uint8(z)
+    assert got.dtype == np.uint8 and got.shape == (n, 3, 64, 64) and np.array_equal(got, want)
+    m.close()
