@@ -276,11 +276,35 @@ def main():
                 model.sample_at(z)
                 lat2.append((time.perf_counter() - t) * 1e3)
             del os.environ["IAN_NO_DEC_CACHE"]
+            # photo mode (NPE.py:218-231): brush step + blend; the blend runs on the device chained after the decoder
+            from neural_photo_editor_amd import npe_ops
+            IMG = np.uint8((O.make_images(1, seed=9)[0] + 1.0) * 127.5)
+            RECON = model.sample_at_uint8(model.encode_images(np.asarray([npe_ops.to_tanh(IMG)], dtype=np.float32)))[0]
+            ERROR = npe_ops.to_tanh(np.float32(IMG)) - npe_ops.to_tanh(np.float32(RECON))
+            lat3 = []
+            for i in range(80):
+                t = time.perf_counter()
+                g = model.imgradRGB(c1, r1, c2, r2, rgb, z)
+                z = z - 0.05 * g * (1 + (c2 - c1))
+                model.photo_blend(z, RECON, ERROR)
+                lat3.append((time.perf_counter() - t) * 1e3)
+            h.set_option("edit_graph", 0)       # the same loop with eager launches (round-1 behaviour) for comparison
+            lat4 = []
+            for i in range(60):
+                t = time.perf_counter()
+                g = model.imgradRGB(c1, r1, c2, r2, rgb, z)
+                z = z - 0.05 * g * (1 + (c2 - c1))
+                model.sample_at(z)
+                lat4.append((time.perf_counter() - t) * 1e3)
+            h.set_option("edit_graph", 1)
             edit = {"p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)), "steps": len(lat),
                     "p50_ms_no_forward_cache": float(np.percentile(lat2[10:], 50)),
+                    "p50_ms_eager_launches": float(np.percentile(lat4[10:], 50)),
+                    "p50_ms_photo_mode": float(np.percentile(lat3[20:], 50)),
                     "update": "gradient descent (reference, NPE.py:199-209)",
-                    "calls": "imgradRGB + sample_at through the API.py surface (host numpy in/out); imgradRGB reuses the "
-                             "decoder activations sample_at left for the same latent",
+                    "calls": "imgradRGB + sample_at through the API.py surface (host numpy in/out); batch-1 host calls replay captured "
+                             "hipGraphs on an internal stream; imgradRGB reuses the decoder activations sample_at left for the same "
+                             "latent; photo mode = imgradRGB + the device blend of NPE.py:218-231 (12 KB uint8 image back)",
                     "includes": "host<->device copies of z, rgb, image"}
         host_io = None
         if args.host_io:

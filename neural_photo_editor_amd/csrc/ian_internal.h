@@ -119,6 +119,8 @@ hipError_t launch_nhwc_to_nchw(const float* src, int stride, float* dst, int n, 
 // loss seeds for the latent-brush gradients (API.py:59,64): writes d loss / d x_hat (NCHW [1,3,H,W], zero outside patch)
 hipError_t launch_patch_seed(const float* xhat, const float* rgb, float* g, int H, int W, int c1, int r1, int c2,
                              int r2, int mode, hipStream_t s);
+hipError_t launch_patch_seed_dev(const float* xhat, const float* rgb, float* g, int H, int W, const int* patch, int mode,
+                                 hipStream_t s);
 // backward of dec_out-like layer: g NCHW [n,Cout,2H,2W] (already multiplied by act') -> dx NHWC [n,H,W,Cin]
 hipError_t launch_deconv_out_bwd(const float* g, const float* w, float* dx, const float* yfwd, const float* scale,
                                  int n, int H, int W, int Cin, int Cout, int act, hipStream_t s);

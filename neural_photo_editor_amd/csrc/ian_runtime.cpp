@@ -111,6 +111,7 @@ struct Options {
   int tg_nosplit_min_out = 1 << 30;  // outputs (M*Cout) above which 64x64 is forced even if it under-fills
   int mdc_head = 2;                  // few-filter MDCL layers: 0 = tapgemm, 1 = VALU head kernel, 2 = + sibling layers fused
   int tg_variant = 2;                // K-loop schedule of tapgemm_kernel (kernels_tapgemm.hip); autotune picks per layer
+  int edit_graph = 1;                // batch-1 host-pointer calls (the NPE edit loop) replay captured hipGraphs
   int head_fused = 1;                // RGB-Beta head as head6 + head_tail (kernels_head.hip) when the graph matches IAN.py:183-207
   int head_fused_min_n = 8;          // ... for batches of at least this many images (the latent brush's batch-1 backward
                                      // needs the per-layer activations of the unfused ops)
@@ -166,6 +167,23 @@ struct ian_handle {
   size_t u8_cap = 0;
   bool dec_cache_valid = false;
   HeadPlan head;
+  // Interactive loop (NPE.py:192-235): batch-1 calls with HOST pointers on the default stream run on an internal stream
+  // and, from the third call on, replay a captured hipGraph (decoder forward; backward chain per loss kind), removing
+  // the ~15 launches x 3-4 us of host launch time per call.  alloc_epoch counts (re)allocations of anything a captured
+  // kernel argument may point to; a graph captured under an older epoch is dropped and re-captured.
+  struct EditGraph {
+    hipGraphExec_t exec = nullptr;
+    long long epoch = -1;
+    int warm = 0;
+  };
+  long long alloc_epoch = 0;
+  hipStream_t edit_stream = nullptr;
+  float* pin = nullptr;      // pinned host block: z [0,128) | dz [128,256) | image [256, 256+12288) | patch (4 ints) after that
+  int* d_patch = nullptr;
+  EditGraph g_fwd, g_bwd[2];
+  bool graph_failed = false;
+  hipStream_t last_stream = nullptr;   // stream of the last call that left work un-synchronised (or nullptr)
+  bool last_pending = false;
   // profiling
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -221,6 +239,7 @@ int upload(ian_handle* h, const std::vector<T>& v, T** dptr) {
   }
   HIPCHK(h, hipMalloc((void**)dptr, v.size() * sizeof(T)));
   HIPCHK(h, hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  ++h->alloc_epoch;
   return 0;
 }
 
@@ -726,6 +745,7 @@ int get_schedule(ian_handle* h, TgLayer& L, int nimg, Schedule** out) {
       if (h->d_slab) HIPCHK(h, hipFree(h->d_slab));
       HIPCHK(h, hipMalloc((void**)&h->d_slab, need * sizeof(float)));
       h->slab_cap = need;
+      ++h->alloc_epoch;
     }
     it = L.sched.emplace(nimg, std::move(S)).first;
   }
@@ -759,6 +779,7 @@ int ensure_slot(ian_handle* h, int slot, int n, bool grad = false) {
     HIPCHK(h, hipMalloc((void**)&ptr, need * sizeof(float)));
     HIPCHK(h, hipMemset(ptr, 0, need * sizeof(float)));  // channel padding must stay zero
     cap = need;
+    ++h->alloc_epoch;
   }
   return 0;
 }
@@ -1221,6 +1242,7 @@ int stage_in(ian_handle* h, const float* src, size_t count, float** buf, size_t*
     if (*buf) HIPCHK(h, hipFree(*buf));
     HIPCHK(h, hipMalloc((void**)buf, count * sizeof(float)));
     *cap = count;
+    ++h->alloc_epoch;
   }
   HIPCHK(h, hipMemcpyAsync(*buf, src, count * sizeof(float), hipMemcpyHostToDevice, st));
   *out = *buf;
@@ -1257,10 +1279,12 @@ int get_latent_output(ian_handle* h, int slot, float* z, int n, hipStream_t st) 
     if (h->d_stage_out) HIPCHK(h, hipFree(h->d_stage_out));
     HIPCHK(h, hipMalloc((void**)&h->d_stage_out, count * sizeof(float)));
     h->stage_out_cap = count;
+    ++h->alloc_epoch;
   }
   HIPCHK(h, launch_rows_copy(zs.d, zs.cs, h->d_stage_out, zs.c, n, zs.c, st));
   HIPCHK(h, hipMemcpyAsync(z, h->d_stage_out, count * sizeof(float), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
+  h->last_pending = false;
   return 0;
 }
 
@@ -1269,7 +1293,10 @@ int get_image_output(ian_handle* h, float* x, int n, hipStream_t st) {
   const size_t count = os.per_image() * (size_t)n;
   const bool dev = is_device_ptr(x);
   HIPCHK(h, hipMemcpyAsync(x, os.d, count * sizeof(float), dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
-  if (!dev) HIPCHK(h, hipStreamSynchronize(st));
+  if (!dev) {
+    HIPCHK(h, hipStreamSynchronize(st));
+    h->last_pending = false;
+  }
   return 0;
 }
 
@@ -1313,7 +1340,8 @@ struct ProducerEpi {
   int scale_period = 0;
 };
 
-int run_decoder_backward(ian_handle* h, int mode, int c1, int r1, int c2, int r2, const float* d_rgb, hipStream_t st) {
+int run_decoder_backward(ian_handle* h, int mode, int c1, int r1, int c2, int r2, const float* d_rgb, hipStream_t st,
+                         const int* d_patch = nullptr) {
   std::vector<OpPlan*> dec;
   for (auto& op : h->ops)
     if (op.d.segment == IAN_SEG_DEC) dec.push_back(&op);
@@ -1326,8 +1354,12 @@ int run_decoder_backward(ian_handle* h, int mode, int c1, int r1, int c2, int r2
   Slot& out = h->slots[last.d.dst];
   const int H = out.h, W = out.w;
   if (c1 < 0 || r1 < 0 || c2 > W || r2 > H) return fail(h, -7, "patch (%d,%d,%d,%d) outside the %dx%d image", c1, r1, c2, r2, W, H);
-  if (!h->d_gseed) HIPCHK(h, hipMalloc((void**)&h->d_gseed, (size_t)3 * H * W * sizeof(float)));
-  HIPCHK(h, launch_patch_seed(out.d, d_rgb, h->d_gseed, H, W, c1, r1, c2, r2, mode, st));  // dL/dX_hat, NCHW
+  if (!h->d_gseed) {
+    HIPCHK(h, hipMalloc((void**)&h->d_gseed, (size_t)3 * H * W * sizeof(float)));
+    ++h->alloc_epoch;
+  }
+  if (d_patch) HIPCHK(h, launch_patch_seed_dev(out.d, d_rgb, h->d_gseed, H, W, d_patch, mode, st));
+  else HIPCHK(h, launch_patch_seed(out.d, d_rgb, h->d_gseed, H, W, c1, r1, c2, r2, mode, st));  // dL/dX_hat, NCHW
 
   std::vector<char> touched(nslots, 0);
   auto epi_of = [&](int slot) {  // what turns a value-gradient of `slot` into its producer's pre-epilogue gradient
@@ -1422,14 +1454,128 @@ int run_decoder_backward(ian_handle* h, int mode, int c1, int r1, int c2, int r2
   return 0;
 }
 
+// ----- stream hand-over between calls ------------------------------------------------------------------------
+// The handle's buffers are shared by every call; a call that returns without synchronising (device output pointers)
+// leaves work pending on its stream.  When the next call runs on ANOTHER stream, wait for that work first.
+void enter_stream(ian_handle* h, hipStream_t st) {
+  if (h->last_pending && h->last_stream != st) (void)hipStreamSynchronize(h->last_stream);
+  h->last_stream = st;
+  h->last_pending = true;   // cleared by callers that synchronise before returning
+}
+
+// ----- captured graphs for the interactive loop ----------------------------------------------------------------
+constexpr int PIN_Z = 0, PIN_DZ = 128, PIN_IMG = 256, PIN_FLOATS = 256 + 3 * 64 * 64 + 8;
+
+bool edit_graph_eligible(const ian_handle* h, void* stream, std::initializer_list<const void*> host_ptrs) {
+  if (!h->opt.edit_graph || h->prof || stream != nullptr || h->graph_failed || h->desc.num_latents > 128) return false;
+  const Slot& os = h->slots[h->desc.out_slot];
+  if (os.per_image() > 3 * 64 * 64) return false;
+  for (const void* p : host_ptrs)
+    if (p && is_device_ptr(p)) return false;
+  return true;
+}
+
+int edit_ctx(ian_handle* h) {
+  if (h->edit_stream) return 0;
+  HIPCHK(h, hipStreamCreateWithFlags(&h->edit_stream, hipStreamNonBlocking));
+  HIPCHK(h, hipHostMalloc((void**)&h->pin, PIN_FLOATS * sizeof(float), hipHostMallocDefault));
+  HIPCHK(h, hipMalloc((void**)&h->d_patch, 4 * sizeof(int)));
+  if (128 > h->stage_in_cap) {
+    if (h->d_stage_in) HIPCHK(h, hipFree(h->d_stage_in));
+    HIPCHK(h, hipMalloc((void**)&h->d_stage_in, 128 * sizeof(float)));
+    h->stage_in_cap = 128;
+  }
+  if (128 > h->stage_out_cap) {
+    if (h->d_stage_out) HIPCHK(h, hipFree(h->d_stage_out));
+    HIPCHK(h, hipMalloc((void**)&h->d_stage_out, 128 * sizeof(float)));
+    h->stage_out_cap = 128;
+  }
+  ++h->alloc_epoch;
+  return 0;
+}
+
+// Run `body` (a fixed sequence of launches / async copies on h->edit_stream): eagerly the first times (allocations,
+// schedule uploads, function attributes happen there), then captured once, then replayed.
+template <typename F>
+int run_or_replay(ian_handle* h, ian_handle::EditGraph& G, F&& body) {
+  hipStream_t st = h->edit_stream;
+  if (G.exec && G.epoch == h->alloc_epoch) {
+    HIPCHK(h, hipGraphLaunch(G.exec, st));
+    return 0;
+  }
+  if (G.exec) {
+    (void)hipGraphExecDestroy(G.exec);
+    G.exec = nullptr;
+    G.warm = 0;
+  }
+  if (G.warm < 1 || h->graph_failed) {
+    const long long e0 = h->alloc_epoch;
+    const int rc = body();
+    G.warm = (h->alloc_epoch == e0) ? G.warm + 1 : 0;   // something was (re)allocated: run eagerly once more
+    return rc;
+  }
+  const long long e0 = h->alloc_epoch;
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    h->graph_failed = true;
+    return body();
+  }
+  const int rc = body();
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(st, &g);
+  if (rc || e != hipSuccess || !g || h->alloc_epoch != e0) {   // never replay a graph whose capture hit an error or an allocation
+    (void)hipGetLastError();
+    if (g) (void)hipGraphDestroy(g);
+    h->graph_failed = true;
+    h->err.clear();
+    return body();
+  }
+  const hipError_t ei = hipGraphInstantiate(&G.exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (ei != hipSuccess) {
+    (void)hipGetLastError();
+    G.exec = nullptr;
+    h->graph_failed = true;
+    return body();
+  }
+  G.epoch = h->alloc_epoch;
+  HIPCHK(h, hipGraphLaunch(G.exec, st));
+  return 0;
+}
+
+bool dec_cache_hit(const ian_handle* h, const float* z) {
+  return h->dec_cache_valid && !is_device_ptr(z) && getenv("IAN_NO_DEC_CACHE") == nullptr &&
+         memcmp(h->dec_cache_z.data(), z, sizeof(float) * h->desc.num_latents) == 0;
+}
+
+// batch-1 decoder forward for the HOST latent z on the internal stream (graph replay), unless the resident activations
+// already belong to it
+int decode_one_graph(ian_handle* h, const float* z) {
+  if (dec_cache_hit(h, z)) return 0;
+  h->dec_cache_valid = false;
+  int rc;
+  if ((rc = ensure_slot(h, h->desc.z_slot, 1))) return rc;
+  const int zl = h->desc.num_latents;
+  memcpy(h->pin + PIN_Z, z, zl * sizeof(float));
+  hipStream_t st = h->edit_stream;
+  rc = run_or_replay(h, h->g_fwd, [&]() -> int {
+    Slot& zs = h->slots[h->desc.z_slot];
+    HIPCHK(h, hipMemcpyAsync(h->d_stage_in, h->pin + PIN_Z, zl * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(h, launch_rows_copy(h->d_stage_in, zs.c, zs.d, zs.cs, 1, zs.c, st));
+    return run_segment(h, IAN_SEG_DEC, 1, st);
+  });
+  if (rc) return rc;
+  h->dec_cache_z.assign(z, z + zl);
+  h->dec_cache_valid = true;
+  return 0;
+}
+
 // batch-1 decoder forward for latent z unless the resident activations already belong to it (NPE.py:205,218:
 // imgradRGB(z) right after sample_at(z), the blend right after the brush step)
 int decode_one_cached(ian_handle* h, const float* z, hipStream_t st) {
   int rc;
   const bool host_z = !is_device_ptr(z);
-  const bool hit = h->dec_cache_valid && host_z && getenv("IAN_NO_DEC_CACHE") == nullptr &&
-                   memcmp(h->dec_cache_z.data(), z, sizeof(float) * h->desc.num_latents) == 0;
-  if (!hit) {
+  if (!dec_cache_hit(h, z)) {
     h->dec_cache_valid = false;
     if ((rc = set_latent_input(h, h->desc.z_slot, z, 1, st))) return rc;
     if ((rc = run_segment(h, IAN_SEG_DEC, 1, st))) return rc;
@@ -1441,32 +1587,67 @@ int decode_one_cached(ian_handle* h, const float* z, hipStream_t st) {
   return 0;
 }
 
+int upload_rgb_if_changed(ian_handle* h, const float* rgb, hipStream_t st, const float** d_rgb) {
+  Slot& out = h->slots[h->desc.out_slot];
+  const size_t cnt = out.per_image();
+  if (is_device_ptr(rgb)) {
+    *d_rgb = rgb;
+    return 0;
+  }
+  if (!h->d_rgb) {
+    HIPCHK(h, hipMalloc((void**)&h->d_rgb, cnt * sizeof(float)));
+    ++h->alloc_epoch;
+  }
+  // the brush colour image rarely changes between motion events (NPE.py:205 passes the same myRGB): re-upload only when
+  // the host bytes differ from the last upload
+  if (h->rgb_cache.size() != cnt || memcmp(h->rgb_cache.data(), rgb, cnt * sizeof(float)) != 0) {
+    h->rgb_cache.assign(rgb, rgb + cnt);   // the shadow copy is the upload source: it outlives the caller's buffer
+    HIPCHK(h, hipMemcpyAsync(h->d_rgb, h->rgb_cache.data(), cnt * sizeof(float), hipMemcpyHostToDevice, st));
+  }
+  *d_rgb = h->d_rgb;
+  return 0;
+}
+
 int grad_common(ian_handle* h, int mode, int c1, int r1, int c2, int r2, const float* rgb, const float* z, float* dz,
                 void* stream) {
   int rc = check_ready(h, 1);
   if (rc) return rc;
+  if (!z || !dz) return fail(h, -1, "null pointer passed to ian_grad_*");
+  Slot& zs = h->slots[h->desc.z_slot];
+  if (edit_graph_eligible(h, stream, {z, dz, rgb})) {
+    Slot& out = h->slots[h->desc.out_slot];
+    if (c1 < 0 || r1 < 0 || c2 > out.w || r2 > out.h) return fail(h, -7, "patch (%d,%d,%d,%d) outside the %dx%d image", c1, r1, c2, r2, out.w, out.h);
+    if ((rc = edit_ctx(h))) return rc;
+    hipStream_t st = h->edit_stream;
+    enter_stream(h, st);
+    if ((rc = decode_one_graph(h, z))) return rc;
+    const float* d_rgb = nullptr;
+    if (mode == 1 && (rc = upload_rgb_if_changed(h, rgb, st, &d_rgb))) return rc;
+    if ((rc = ensure_slot(h, h->desc.z_slot, 1, true))) return rc;
+    int* patch = reinterpret_cast<int*>(h->pin + PIN_IMG + 3 * 64 * 64);
+    patch[0] = c1; patch[1] = r1; patch[2] = c2; patch[3] = r2;
+    rc = run_or_replay(h, h->g_bwd[mode], [&]() -> int {
+      HIPCHK(h, hipMemcpyAsync(h->d_patch, patch, 4 * sizeof(int), hipMemcpyHostToDevice, st));
+      int r = run_decoder_backward(h, mode, 0, 0, out.w, out.h, d_rgb, st, h->d_patch);
+      if (r) return r;
+      HIPCHK(h, launch_rows_copy(zs.g, zs.cs, h->d_stage_out, zs.c, 1, zs.c, st));
+      HIPCHK(h, hipMemcpyAsync(h->pin + PIN_DZ, h->d_stage_out, zs.c * sizeof(float), hipMemcpyDeviceToHost, st));
+      return 0;
+    });
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(st));
+    h->last_pending = false;
+    memcpy(dz, h->pin + PIN_DZ, zs.c * sizeof(float));
+    return 0;
+  }
   hipStream_t st = (hipStream_t)stream;
+  enter_stream(h, st);
   TotalTimer tt(h, st);
   if ((rc = decode_one_cached(h, z, st))) return rc;
   const float* d_rgb = nullptr;
-  if (mode == 1) {
-    Slot& out = h->slots[h->desc.out_slot];
-    const size_t cnt = out.per_image();
-    if (is_device_ptr(rgb)) d_rgb = rgb;
-    else {
-      if (!h->d_rgb) HIPCHK(h, hipMalloc((void**)&h->d_rgb, cnt * sizeof(float)));
-      // the brush colour image rarely changes between motion events (NPE.py:205 passes the same myRGB): re-upload
-      // only when the host bytes differ from the last upload
-      if (h->rgb_cache.size() != cnt || memcmp(h->rgb_cache.data(), rgb, cnt * sizeof(float)) != 0) {
-        HIPCHK(h, hipMemcpyAsync(h->d_rgb, rgb, cnt * sizeof(float), hipMemcpyHostToDevice, st));
-        h->rgb_cache.assign(rgb, rgb + cnt);
-      }
-      d_rgb = h->d_rgb;
-    }
-  }
+  if (mode == 1 && (rc = upload_rgb_if_changed(h, rgb, st, &d_rgb))) return rc;
   if ((rc = run_decoder_backward(h, mode, c1, r1, c2, r2, d_rgb, st))) return rc;
   // result sits in the gradient buffer of the z slot
-  Slot& zs = h->slots[h->desc.z_slot];
   if (is_device_ptr(dz)) {
     HIPCHK(h, launch_rows_copy(zs.g, zs.cs, dz, zs.c, 1, zs.c, st));
   } else {
@@ -1474,10 +1655,12 @@ int grad_common(ian_handle* h, int mode, int c1, int r1, int c2, int r2, const f
       if (h->d_stage_out) HIPCHK(h, hipFree(h->d_stage_out));
       HIPCHK(h, hipMalloc((void**)&h->d_stage_out, zs.c * sizeof(float)));
       h->stage_out_cap = zs.c;
+      ++h->alloc_epoch;
     }
     HIPCHK(h, launch_rows_copy(zs.g, zs.cs, h->d_stage_out, zs.c, 1, zs.c, st));
     HIPCHK(h, hipMemcpyAsync(dz, h->d_stage_out, zs.c * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
+    h->last_pending = false;
   }
   return 0;
 }
@@ -1601,6 +1784,7 @@ int ian_encode_pre_iaf(ian_handle* h, const float* x, int32_t n, float* z, void*
   int rc = check_ready(h, n);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  enter_stream(h, st);
   TotalTimer tt(h, st);
   if ((rc = set_image_input(h, x, n, st))) return rc;
   if ((rc = run_segment(h, IAN_SEG_ENC, n, st))) return rc;
@@ -1611,6 +1795,7 @@ int ian_encode(ian_handle* h, const float* x, int32_t n, float* z, void* stream)
   int rc = check_ready(h, n);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  enter_stream(h, st);
   TotalTimer tt(h, st);
   h->dec_cache_valid = false;
   if ((rc = set_image_input(h, x, n, st))) return rc;
@@ -1623,6 +1808,7 @@ int ian_iaf(ian_handle* h, const float* zpre, int32_t n, float* z, void* stream)
   int rc = check_ready(h, n);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  enter_stream(h, st);
   h->dec_cache_valid = false;
   if ((rc = set_latent_input(h, h->desc.zpre_slot, zpre, n, st))) return rc;
   if ((rc = run_segment(h, IAN_SEG_IAF, n, st))) return rc;
@@ -1632,7 +1818,21 @@ int ian_iaf(ian_handle* h, const float* zpre, int32_t n, float* z, void* stream)
 int ian_decode(ian_handle* h, const float* z, int32_t n, float* x, void* stream) {
   int rc = check_ready(h, n);
   if (rc) return rc;
+  if (!z || !x) return fail(h, -1, "null pointer passed to ian_decode");
+  if (n == 1 && edit_graph_eligible(h, stream, {z, x})) {   // NPE.py:110,218,261: one latent, host buffers
+    if ((rc = edit_ctx(h))) return rc;
+    hipStream_t st = h->edit_stream;
+    enter_stream(h, st);
+    if ((rc = decode_one_graph(h, z))) return rc;
+    Slot& os = h->slots[h->desc.out_slot];
+    HIPCHK(h, hipMemcpyAsync(h->pin + PIN_IMG, os.d, os.per_image() * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    h->last_pending = false;
+    memcpy(x, h->pin + PIN_IMG, os.per_image() * sizeof(float));
+    return 0;
+  }
   hipStream_t st = (hipStream_t)stream;
+  enter_stream(h, st);
   TotalTimer tt(h, st);
   h->dec_cache_valid = false;
   if ((rc = set_latent_input(h, h->desc.z_slot, z, n, st))) return rc;
@@ -1649,6 +1849,7 @@ int ian_reconstruct(ian_handle* h, const float* x, int32_t n, float* xhat, void*
   int rc = check_ready(h, n);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  enter_stream(h, st);
   TotalTimer tt(h, st);
   h->dec_cache_valid = false;
   if ((rc = set_image_input(h, x, n, st))) return rc;
@@ -1663,8 +1864,16 @@ int ian_decode_u8(ian_handle* h, const float* z, int32_t n, uint8_t* out, void* 
   if (rc) return rc;
   if (!z || !out) return fail(h, -1, "null pointer passed to ian_decode_u8");
   hipStream_t st = (hipStream_t)stream;
+  const bool graph = n == 1 && edit_graph_eligible(h, stream, {z, out});
+  if (graph) {
+    if ((rc = edit_ctx(h))) return rc;
+    st = h->edit_stream;
+  }
+  enter_stream(h, st);
   TotalTimer tt(h, st);
-  if (n == 1) {
+  if (graph) {
+    if ((rc = decode_one_graph(h, z))) return rc;
+  } else if (n == 1) {
     if ((rc = decode_one_cached(h, z, st))) return rc;
   } else {
     h->dec_cache_valid = false;
@@ -1685,6 +1894,7 @@ int ian_decode_u8(ian_handle* h, const float* z, int32_t n, uint8_t* out, void* 
   HIPCHK(h, launch_to_uint8(os.d, h->d_u8, (long long)count, st));
   HIPCHK(h, hipMemcpyAsync(out, h->d_u8, count, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
+  h->last_pending = false;
   return 0;
 }
 
@@ -1697,8 +1907,16 @@ int ian_photo_blend(ian_handle* h, const float* z, const uint8_t* recon, const f
   Slot& os = h->slots[h->desc.out_slot];
   if (os.h != 64 || os.w != 64 || os.c != 3) return fail(h, -7, "ian_photo_blend needs a 3x64x64 image");
   hipStream_t st = (hipStream_t)stream;
+  const bool graph = edit_graph_eligible(h, stream, {z, recon, error, im, mask});
+  if (graph) {
+    if ((rc = edit_ctx(h))) return rc;
+    st = h->edit_stream;
+  }
+  enter_stream(h, st);
   TotalTimer tt(h, st);
-  if ((rc = decode_one_cached(h, z, st))) return rc;
+  if (graph) {
+    if ((rc = decode_one_graph(h, z))) return rc;
+  } else if ((rc = decode_one_cached(h, z, st))) return rc;
   const size_t cnt = 3 * 64 * 64;
   PhotoBlendArgs a;
   memset(&a, 0, sizeof a);
@@ -1707,8 +1925,8 @@ int ian_photo_blend(ian_handle* h, const float* z, const uint8_t* recon, const f
   else {
     if (!h->d_recon) HIPCHK(h, hipMalloc((void**)&h->d_recon, cnt));
     if (h->recon_cache.size() != cnt || memcmp(h->recon_cache.data(), recon, cnt) != 0) {   // changes on infer / Reset only
-      HIPCHK(h, hipMemcpyAsync(h->d_recon, recon, cnt, hipMemcpyHostToDevice, st));
       h->recon_cache.assign(recon, recon + cnt);
+      HIPCHK(h, hipMemcpyAsync(h->d_recon, h->recon_cache.data(), cnt, hipMemcpyHostToDevice, st));
     }
     a.recon = h->d_recon;
   }
@@ -1716,8 +1934,8 @@ int ian_photo_blend(ian_handle* h, const float* z, const uint8_t* recon, const f
   else {
     if (!h->d_error) HIPCHK(h, hipMalloc((void**)&h->d_error, cnt * sizeof(float)));
     if (h->error_cache.size() != cnt || memcmp(h->error_cache.data(), error, cnt * sizeof(float)) != 0) {
-      HIPCHK(h, hipMemcpyAsync(h->d_error, error, cnt * sizeof(float), hipMemcpyHostToDevice, st));
       h->error_cache.assign(error, error + cnt);
+      HIPCHK(h, hipMemcpyAsync(h->d_error, h->error_cache.data(), cnt * sizeof(float), hipMemcpyHostToDevice, st));
     }
     a.error = h->d_error;
   }
@@ -1731,7 +1949,10 @@ int ian_photo_blend(ian_handle* h, const float* z, const uint8_t* recon, const f
   HIPCHK(h, launch_photo_blend(a, st));
   if (!im_dev) HIPCHK(h, hipMemcpyAsync(im, h->d_im, cnt, hipMemcpyDeviceToHost, st));
   if (mask && !mask_dev) HIPCHK(h, hipMemcpyAsync(mask, h->d_mask, 64 * 64 * sizeof(double), hipMemcpyDeviceToHost, st));
-  if (!im_dev || (mask && !mask_dev)) HIPCHK(h, hipStreamSynchronize(st));
+  if (!im_dev || (mask && !mask_dev)) {
+    HIPCHK(h, hipStreamSynchronize(st));
+    h->last_pending = false;
+  }
   return 0;
 }
 
@@ -1740,6 +1961,8 @@ int ian_autotune(ian_handle* h, int32_t n, int32_t what, void* stream) {
   if (rc) return rc;
   h->dec_cache_valid = false;
   hipStream_t st = (hipStream_t)stream;
+  enter_stream(h, st);
+  ++h->alloc_epoch;   // schedules are rebuilt below
   const bool prof = h->prof;
   h->prof = false;
   const bool verbose = getenv("IAN_DEBUG") != nullptr;
@@ -1829,6 +2052,7 @@ static int read_slot_impl(ian_handle* h, int32_t slot, int32_t n, float* out, vo
   if (rc) return rc;
   if (slot < 0 || slot >= (int)h->slots.size()) return fail(h, -1, "bad slot %d", slot);
   hipStream_t st = (hipStream_t)stream;
+  enter_stream(h, st);
   Slot s = h->slots[slot];
   if (grad) {
     s.d = s.g;
@@ -1909,12 +2133,14 @@ int ian_set_option(ian_handle* h, const char* key, int32_t value) {
   else if (k == "tg_variant") h->opt.tg_variant = value;
   else if (k == "mdc_head") h->opt.mdc_head = value;
   else if (k == "head_fused") h->opt.head_fused = value;
+  else if (k == "edit_graph") h->opt.edit_graph = value;
   else if (k == "head_fused_min_n") h->opt.head_fused_min_n = std::max(1, value);
   else return fail(h, -1, "unknown option '%s'", key);
   for (auto& op : h->ops) {  // schedules depend on the options
     free_schedules(op.fwd);
     free_schedules(op.bwd);
   }
+  ++h->alloc_epoch;
   return 0;
 }
 
@@ -1938,6 +2164,11 @@ void ian_destroy(ian_handle* h) {
   for (float* p : {h->d_slab, h->d_stage_in, h->d_stage_out, h->d_gseed, h->d_rgb, h->head.d_ftab, h->head.d_comp})
     if (p) (void)hipFree(p);
   if (h->head.d_itab) (void)hipFree(h->head.d_itab);
+  for (ian_handle::EditGraph* g : {&h->g_fwd, &h->g_bwd[0], &h->g_bwd[1]})
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (h->edit_stream) (void)hipStreamDestroy(h->edit_stream);
+  if (h->pin) (void)hipHostFree(h->pin);
+  if (h->d_patch) (void)hipFree(h->d_patch);
   for (void* p : {(void*)h->d_recon, (void*)h->d_error, (void*)h->d_im, (void*)h->d_mask, (void*)h->d_u8})
     if (p) (void)hipFree(p);
   for (auto& e : h->ev_pool) {

@@ -510,6 +510,29 @@ __global__ __launch_bounds__(256) void patch_seed_kernel(const float* __restrict
   }
   g[i] = v;
 }
+// the same with the rectangle read from device memory (patch = {c1, r1, c2, r2}): nothing in the launch depends on the
+// brush position, so the whole latent-brush step can be replayed from a captured graph while the brush moves
+__global__ __launch_bounds__(256) void patch_seed_dev_kernel(const float* __restrict__ xhat, const float* __restrict__ rgb,
+                                                             float* __restrict__ g, int H, int W, const int* __restrict__ patch,
+                                                             int mode) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 3 * H * W) return;
+  const int c1 = patch[0], r1 = patch[1], c2 = patch[2], r2 = patch[3];
+  const int xx = i % W, yy = (i / W) % H;
+  const int cnt = 3 * (r2 - r1) * (c2 - c1);
+  float v = 0.f;
+  if (yy >= r1 && yy < r2 && xx >= c1 && xx < c2 && cnt > 0) {
+    const float inv = 1.f / (float)cnt;
+    v = (mode == 0) ? inv : 2.f * (xhat[i] - rgb[i]) * inv;
+  }
+  g[i] = v;
+}
+hipError_t launch_patch_seed_dev(const float* xhat, const float* rgb, float* g, int H, int W, const int* patch, int mode,
+                                 hipStream_t s) {
+  hipLaunchKernelGGL(patch_seed_dev_kernel, dim3((3 * H * W + 255) / 256), dim3(256), 0, s, xhat, rgb, g, H, W, patch, mode);
+  return hipGetLastError();
+}
+
 hipError_t launch_patch_seed(const float* xhat, const float* rgb, float* g, int H, int W, int c1, int r1, int c2,
                              int r2, int mode, hipStream_t s) {
   hipLaunchKernelGGL(patch_seed_kernel, dim3((3 * H * W + 255) / 256), dim3(256), 0, s, xhat, rgb, g, H, W, c1, r1, c2,
