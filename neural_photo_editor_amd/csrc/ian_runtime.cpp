@@ -967,12 +967,11 @@ int find_head_plan(ian_handle* h) {
     P.opR = iR; P.opGa = iGa; P.opGb = iGb; P.opBa = iBa; P.opBb = iBb; P.opCat = iCat; P.opBeta = ib; P.halo = halo;
     P.first = std::min({iR, iGa, iBa});
     // tables: taps grouped by dy (the shift-add of head6_kernel) and the six filters' epilogues
-    std::vector<int> itab(256, 0);
+    std::vector<int> itab(128, 0);
     for (size_t t = 0; t < LR.taps.size(); ++t) {
       const int dyi = LR.taps[t].dy + 4;
-      itab[16 + dyi * 12 + itab[dyi]] = (int)t;
+      itab[16 + dyi * 12 + itab[dyi]] = (int)t | ((LR.taps[t].dx + 64) << 8);
       itab[dyi]++;
-      itab[128 + t] = LR.taps[t].dx;
     }
     std::vector<float> ftab(32, 0.f);
     const int six[3] = {iR, iGa, iBa};

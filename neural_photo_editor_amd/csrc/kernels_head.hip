@@ -77,6 +77,11 @@ __global__ __launch_bounds__(512, 2) void head6_kernel(HeadFusedArgs a) {
     }
   }
   for (int i = tid; i < HD_RING * HD_W * HD_NF; i += 512) ring[i] = 0.f;
+  int* tab = reinterpret_cast<int*>(ring + HD_RING * HD_W * HD_NF);   // [0..8] taps per dy, [16 + 12*dyi + q] packed taps
+  for (int i = tid; i < 128; i += 512) tab[i] = a.itab[i];
+  const int f_own = tid % HD_NF;
+  const float sc_f = a.ftab[f_own], sh_f = a.ftab[8 + f_own];
+  const int act_f = (int)a.ftab[16 + f_own];
 
   // ---- staging of one input row: 64 pixels x 128 channels = 2048 float4, 4 per thread, fully coalesced
   const float* xin = a.x + (size_t)img * a.H * HD_W * a.xs;
@@ -145,36 +150,33 @@ __global__ __launch_bounds__(512, 2) void head6_kernel(HeadFusedArgs a) {
     }
     if (r + 1 < r_end) HD_STORE_ROW(buf ^ 1);  // the other buffer: nobody reads it during this row
     __syncthreads();
-    // ---- shift-add: out[y = r - dy][x][f] += sum over the taps with that dy of Y[x + dx][(t,f)]
-    for (int it = tid; it < 9 * HD_W * HD_NF; it += 512) {
-      const int f = it % HD_NF, x = (it / HD_NF) % HD_W, dyi = it / (HD_W * HD_NF);
-      const int y = r - (dyi - 4);
-      if (y < y0 || y >= y1) continue;
-      float s = 0.f;
-      const int nt = a.itab[dyi];
-      for (int q = 0; q < nt; ++q) {
-        const int t = a.itab[16 + dyi * 12 + q];
-        const int xx = x + a.itab[128 + t];
-        if ((unsigned)xx < (unsigned)HD_W) s += Ys[xx * HD_YS + t * HD_NF + f];
+    // ---- shift-add: out[y = r - dy][x][f] += sum over the taps with that dy of Y[x + dx][(t,f)].  Thread (x,f) owns
+    // its ring column for the whole kernel: the tap walk is wave-uniform (table reads broadcast), its adds and the
+    // finalisation of a completed row need no synchronisation among themselves, and the order is fixed.
+    if (tid < HD_W * HD_NF) {
+      const int f = tid % HD_NF, x = tid / HD_NF;
+      for (int dyi = 0; dyi < 9; ++dyi) {
+        const int y = r - (dyi - 4);
+        if (y < y0 || y >= y1) continue;
+        const int nt = tab[dyi];
+        float s = 0.f;
+        for (int q = 0; q < nt; ++q) {
+          const int e = tab[16 + dyi * 12 + q];          // tap id | (dx + 64) << 8
+          const int t = e & 0xFF, xx = x + (e >> 8) - 64;
+          if ((unsigned)xx < (unsigned)HD_W) s += Ys[xx * HD_YS + t * HD_NF + f];
+        }
+        ring[((y & (HD_RING - 1)) * HD_W + x) * HD_NF + f] += s;
       }
-      ring[((y & (HD_RING - 1)) * HD_W + x) * HD_NF + f] += s;
-    }
-    __syncthreads();
-    // ---- output rows no later input row can reach are complete: y = r - halo, and everything still open after the
-    // image's last row
-    {
+      // output rows no later input row can reach are complete: y = r - halo, and everything still open after the
+      // image's last row
       const int lo = max(y0, r - a.halo), hi = min(y1 - 1, (r == a.H - 1) ? y1 - 1 : r - a.halo);
       for (int yf = lo; yf <= hi; ++yf) {
-        if (tid < HD_W * HD_NF) {
-          const int f = tid % HD_NF, x = tid / HD_NF;
-          float* rp = ring + ((yf & (HD_RING - 1)) * HD_W + x) * HD_NF + f;
-          const float v = hd_act(*rp * a.ftab[f] + a.ftab[8 + f], (int)a.ftab[16 + f]);
-          out[((size_t)yf * HD_W + x) * 8 + f] = v;
-          *rp = 0.f;
-        }
+        float* rp = ring + ((yf & (HD_RING - 1)) * HD_W + x) * HD_NF + f;
+        out[((size_t)yf * HD_W + x) * 8 + f] = hd_act(*rp * sc_f + sh_f, act_f);
+        *rp = 0.f;
       }
     }
-    __syncthreads();  // the resets above are made by other threads than the next row's adds
+    __syncthreads();  // Ys is rewritten by the next row
   }
 }
 
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void head6_kernel(HeadFusedArgs a) {
 
 hipError_t launch_head6(const HeadFusedArgs& a, int n, hipStream_t s) {
   if (a.W != HD_W || a.ntaps * HD_NF > 224 || a.bands < 1 || (a.H % a.bands) || a.halo > 4 || a.xs < HD_CIN) return hipErrorInvalidValue;
-  const size_t lds = (size_t)(2 * HD_W * HD_XS + HD_W * HD_YS + HD_RING * HD_W * HD_NF) * sizeof(float);
+  const size_t lds = (size_t)(2 * HD_W * HD_XS + HD_W * HD_YS + HD_RING * HD_W * HD_NF + 128) * sizeof(float);
   const int ntiles = (a.ntaps * HD_NF + 31) / 32;
 #define HD_LAUNCH(NT)                                                                                             \
   {                                                                                                               \
