@@ -172,7 +172,7 @@ struct HeadFusedArgs {
   const float* x;          // NHWC, pixel stride xs, 128 channels
   const float *w0, *w1, *w2;  // forward slabs [tap][CoutPad][128] of the three layers (rows 0,1 used)
   float* out;              // compact map
-  const int* itab;         // 128 ints: [0..8] taps per dy = -4..4; [16 + 12*dyi + q] = tap id | (dx + 64) << 8
+  const int* itab;         // per tap t: (dy + 4) | (dx + 64) << 8
   const float* ftab;       // [0..5] scale, [8..13] shift, [16..21] activation code of the six filters
   int H, W, xs, ntaps, bands, halo;
   long long w_tap_stride;

@@ -949,7 +949,7 @@ int find_head_plan(ian_handle* h) {
     if (R.cin != 128 || R.in_w != 64 || h->slots[R.src].cs != 128) continue;
     const TgLayer& LR = h->ops[iR].fwd;
     bool ok = same_taps(LR, h->ops[iGa].fwd) && same_taps(LR, h->ops[iBa].fwd) && same_taps(LR, h->ops[iGb].fwd) &&
-              same_taps(LR, h->ops[iBb].fwd) && LR.taps.size() * 6 <= 224 && LR.taps.size() <= 48;
+              same_taps(LR, h->ops[iBb].fwd) && LR.taps.size() <= 37;
     int halo = 0;
     std::vector<int> per_dy(9, 0);
     for (auto& t : LR.taps) {
@@ -967,12 +967,8 @@ int find_head_plan(ian_handle* h) {
     P.opR = iR; P.opGa = iGa; P.opGb = iGb; P.opBa = iBa; P.opBb = iBb; P.opCat = iCat; P.opBeta = ib; P.halo = halo;
     P.first = std::min({iR, iGa, iBa});
     // tables: taps grouped by dy (the shift-add of head6_kernel) and the six filters' epilogues
-    std::vector<int> itab(128, 0);
-    for (size_t t = 0; t < LR.taps.size(); ++t) {
-      const int dyi = LR.taps[t].dy + 4;
-      itab[16 + dyi * 12 + itab[dyi]] = (int)t | ((LR.taps[t].dx + 64) << 8);
-      itab[dyi]++;
-    }
+    std::vector<int> itab(64, 0);
+    for (size_t t = 0; t < LR.taps.size(); ++t) itab[t] = (LR.taps[t].dy + 4) | ((LR.taps[t].dx + 64) << 8);
     std::vector<float> ftab(32, 0.f);
     const int six[3] = {iR, iGa, iBa};
     for (int k = 0; k < 3; ++k)

@@ -42,6 +42,7 @@ constexpr int HD_XS = HD_CIN + 4; // LDS row stride of the staged input row: ds_
 constexpr int HD_NF = 6;          // fused filters
 constexpr int HD_YS = 230;        // LDS row stride of Y: >= 224 and = 6 mod 32 -> the shift-add reads are conflict-free
 constexpr int HD_RING = 16;       // open output rows (power of two >= 9)
+constexpr int HD_MAXT = 37;       // taps: 37 * 6 = 222 <= 224 columns
 
 template <int NTILES>  // N tiles of 32 columns actually holding (tap,filter) pairs: ceil(ntaps*6/32) <= 7
 __global__ __launch_bounds__(512, 2) void head6_kernel(HeadFusedArgs a) {
@@ -77,8 +78,9 @@ __global__ __launch_bounds__(512, 2) void head6_kernel(HeadFusedArgs a) {
     }
   }
   for (int i = tid; i < HD_RING * HD_W * HD_NF; i += 512) ring[i] = 0.f;
-  int* tab = reinterpret_cast<int*>(ring + HD_RING * HD_W * HD_NF);   // [0..8] taps per dy, [16 + 12*dyi + q] packed taps
-  for (int i = tid; i < 128; i += 512) tab[i] = a.itab[i];
+  int tap_e[HD_MAXT];   // (dy + 4) | (dx + 64) << 8 of every tap: wave-uniform, kept in (scalar) registers for the whole kernel
+#pragma unroll
+  for (int t = 0; t < HD_MAXT; ++t) tap_e[t] = (t < a.ntaps) ? a.itab[t] : 0;
   const int f_own = tid % HD_NF;
   const float sc_f = a.ftab[f_own], sh_f = a.ftab[8 + f_own];
   const int act_f = (int)a.ftab[16 + f_own];
@@ -150,22 +152,23 @@ __global__ __launch_bounds__(512, 2) void head6_kernel(HeadFusedArgs a) {
     }
     if (r + 1 < r_end) HD_STORE_ROW(buf ^ 1);  // the other buffer: nobody reads it during this row
     __syncthreads();
-    // ---- shift-add: out[y = r - dy][x][f] += sum over the taps with that dy of Y[x + dx][(t,f)].  Thread (x,f) owns
-    // its ring column for the whole kernel: the tap walk is wave-uniform (table reads broadcast), its adds and the
-    // finalisation of a completed row need no synchronisation among themselves, and the order is fixed.
+    // ---- shift-add: out[y = r - dy_t][x - dx_t][f] += Y[x][(t,f)], gathered: thread (x,f) owns output column x, filter f
+    // of every open row.  Its 33 reads of Y are independent (issued back to back), each lands in the ring through a
+    // fire-and-forget ds_add_f32 on an address only this thread touches -- LDS operations of a wave execute in order, so the
+    // summation order is the tap order: deterministic, and no read-modify-write latency chain.
     if (tid < HD_W * HD_NF) {
       const int f = tid % HD_NF, x = tid / HD_NF;
-      for (int dyi = 0; dyi < 9; ++dyi) {
-        const int y = r - (dyi - 4);
-        if (y < y0 || y >= y1) continue;
-        const int nt = tab[dyi];
-        float s = 0.f;
-        for (int q = 0; q < nt; ++q) {
-          const int e = tab[16 + dyi * 12 + q];          // tap id | (dx + 64) << 8
-          const int t = e & 0xFF, xx = x + (e >> 8) - 64;
-          if ((unsigned)xx < (unsigned)HD_W) s += Ys[xx * HD_YS + t * HD_NF + f];
+      float* my_ring = ring + x * HD_NF + f;
+      const float* my_y = Ys + f;
+#pragma unroll
+      for (int t = 0; t < HD_MAXT; ++t) {
+        if (t < a.ntaps) {                                   // uniform
+          const int y = r - ((tap_e[t] & 0xFF) - 4);         // uniform
+          if (y >= y0 && y < y1) {
+            const int xx = x + ((tap_e[t] >> 8) - 64);
+            if ((unsigned)xx < (unsigned)HD_W) atomicAdd(my_ring + (y & (HD_RING - 1)) * HD_W * HD_NF, my_y[xx * HD_YS + t * HD_NF]);
+          }
         }
-        ring[((y & (HD_RING - 1)) * HD_W + x) * HD_NF + f] += s;
       }
       // output rows no later input row can reach are complete: y = r - halo, and everything still open after the
       // image's last row
@@ -184,8 +187,8 @@ __global__ __launch_bounds__(512, 2) void head6_kernel(HeadFusedArgs a) {
 #undef HD_STORE_ROW
 
 hipError_t launch_head6(const HeadFusedArgs& a, int n, hipStream_t s) {
-  if (a.W != HD_W || a.ntaps * HD_NF > 224 || a.bands < 1 || (a.H % a.bands) || a.halo > 4 || a.xs < HD_CIN) return hipErrorInvalidValue;
-  const size_t lds = (size_t)(2 * HD_W * HD_XS + HD_W * HD_YS + HD_RING * HD_W * HD_NF + 128) * sizeof(float);
+  if (a.W != HD_W || a.ntaps > HD_MAXT || a.bands < 1 || (a.H % a.bands) || a.halo > 4 || a.xs < HD_CIN) return hipErrorInvalidValue;
+  const size_t lds = (size_t)(2 * HD_W * HD_XS + HD_W * HD_YS + HD_RING * HD_W * HD_NF) * sizeof(float);
   const int ntiles = (a.ntaps * HD_NF + 31) / 32;
 #define HD_LAUNCH(NT)                                                                                             \
   {                                                                                                               \

@@ -9,6 +9,7 @@ if os.environ.get("EDIT_EAGER"):
     m.handle.set_option("edit_graph", 0)
 z = O.make_latents(1, seed=2)
 rgb = np.full((1, 3, 64, 64), -1.0, np.float32); rgb[:, 0] = 1.0
+m.reconstruct(O.make_images(1, seed=0))
 m.imgradRGB(26, 26, 30, 30, rgb, z)
 m.handle.autotune(1, 3)
 for i in range(60):
