@@ -89,7 +89,8 @@ static inline TgShape tg_shape(int cfg) {
 }
 
 hipError_t launch_tapgemm(int cfg, const TgParams& p, int nitems, hipStream_t s);
-hipError_t launch_tapgemm_reduce(int cfg, const TgReduceParams& p, int ntiles, hipStream_t s);
+// kp > 1: four lanes share the slabs of one output element (few tiles, many slabs: batch 1)
+hipError_t launch_tapgemm_reduce(int cfg, const TgReduceParams& p, int ntiles, int kp, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // edge layers (3 image channels) and small ops
@@ -124,6 +125,10 @@ hipError_t launch_patch_seed_dev(const float* xhat, const float* rgb, float* g, 
 // backward of dec_out-like layer: g NCHW [n,Cout,2H,2W] (already multiplied by act') -> dx NHWC [n,H,W,Cin]
 hipError_t launch_deconv_out_bwd(const float* g, const float* w, float* dx, const float* yfwd, const float* scale,
                                  int n, int H, int W, int Cin, int Cout, int act, hipStream_t s);
+// batch-1 latent brush: seed (rectangle in device memory) + output activation derivative + the same backward-data, one launch
+hipError_t launch_deconv_out_bwd_seed(const float* xhat, const float* rgb, const int* patch, int mode, int out_act,
+                                      const float* oscale, const float* w, float* dx, const float* yfwd, const float* scale, int H,
+                                      int W, int Cin, int Cout, int act, hipStream_t s);
 // elementwise: g = g * act'(y) * scale  (NCHW small tensors, c channels of hw pixels)
 hipError_t launch_dact_nchw(float* g, const float* y, const float* scale, int n, int c, int hw, int act,
                             hipStream_t s);
@@ -172,7 +177,7 @@ struct HeadFusedArgs {
   const float* x;          // NHWC, pixel stride xs, 128 channels
   const float *w0, *w1, *w2;  // forward slabs [tap][CoutPad][128] of the three layers (rows 0,1 used)
   float* out;              // compact map
-  const int* itab;         // per tap t: (dy + 4) | (dx + 64) << 8
+  const int* itab;         // 44 slots: [0,12) taps with dy = 0, then 4 per dy = -4..-1, 1..4; tap id | (dx+64) << 8, empty = -1
   const float* ftab;       // [0..5] scale, [8..13] shift, [16..21] activation code of the six filters
   int H, W, xs, ntaps, bands, halo;
   long long w_tap_stride;

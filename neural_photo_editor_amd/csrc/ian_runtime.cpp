@@ -45,6 +45,7 @@ struct Schedule {
   int ntiles = 0;  // >0 => split-K: slabs + reduce pass
   TgTile* d_tiles = nullptr;
   size_t slab_tiles = 0;
+  int max_nsplit = 1;
   std::vector<TgItem> h_items;  // kept for tests / debugging
   std::vector<TgTile> h_tiles;
 };
@@ -672,6 +673,7 @@ void build_schedule(const ian_handle* h, const TgLayer& L, int nimg, Schedule& S
   std::vector<Group> groups;
   int gm = std::max(1, h->opt.tg_xcd_group), gn = std::max(1, h->opt.tg_xcd_group);
   S.h_tiles.clear();
+  S.max_nsplit = 1;
   size_t slab_next = 0;
   // tile -> slab bookkeeping
   std::vector<std::vector<int>> nsplit_c(ncls);
@@ -681,6 +683,7 @@ void build_schedule(const ian_handle* h, const TgLayer& L, int nimg, Schedule& S
     if (split) ns = std::max(1, (ksteps + steps_per_item - 1) / steps_per_item);
     const int per = (ksteps + ns - 1) / ns;
     ns = (ksteps + per - 1) / per;
+    if (split) S.max_nsplit = std::max(S.max_nsplit, ns);
     // slab indices: tile-major so that the reduce pass reads contiguous slabs
     std::vector<int> slab0((size_t)tiles_m * tiles_n, -1);
     if (split) {
@@ -830,7 +833,7 @@ int run_tapgemm(ian_handle* h, TgLayer& L, int nimg, const float* x, float* y, i
     r.slab = h->d_slab; r.y = y; r.tiles = S->d_tiles; r.classes = L.d_classes; r.epi = epi;
     r.M = p.M; r.qw_shift = p.qw_shift; r.qhw_shift = p.qhw_shift; r.so = L.so; r.OH = L.OH; r.OW = L.OW;
     r.Cout = L.Cout; r.y_stride = y_stride;
-    HIPCHK(h, launch_tapgemm_reduce(S->cfg, r, S->ntiles, st));
+    HIPCHK(h, launch_tapgemm_reduce(S->cfg, r, S->ntiles, S->max_nsplit >= 8 ? 4 : 1, st));
   }
   if (ev) {
     HIPCHK(h, hipEventRecord(ev->second, st));
@@ -967,8 +970,15 @@ int find_head_plan(ian_handle* h) {
     P.opR = iR; P.opGa = iGa; P.opGb = iGb; P.opBa = iBa; P.opBb = iBb; P.opCat = iCat; P.opBeta = ib; P.halo = halo;
     P.first = std::min({iR, iGa, iBa});
     // tables: taps grouped by dy (the shift-add of head6_kernel) and the six filters' epilogues
-    std::vector<int> itab(64, 0);
-    for (size_t t = 0; t < LR.taps.size(); ++t) itab[t] = (LR.taps[t].dy + 4) | ((LR.taps[t].dx + 64) << 8);
+    std::vector<int> itab(44, -1);   // head6_kernel's static slot layout
+    std::vector<int> used(9, 0);
+    for (size_t t = 0; t < LR.taps.size() && ok; ++t) {
+      const int dy = LR.taps[t].dy, g = dy == 0 ? 0 : (dy < 0 ? dy + 5 : dy + 4);
+      const int cap = g == 0 ? 12 : 4, s0 = g == 0 ? 0 : 12 + (g - 1) * 4;
+      if (used[g] >= cap || LR.taps[t].dx < -63 || LR.taps[t].dx > 63) { ok = false; break; }
+      itab[s0 + used[g]++] = (int)t | ((LR.taps[t].dx + 64) << 8);
+    }
+    if (!ok) continue;
     std::vector<float> ftab(32, 0.f);
     const int six[3] = {iR, iGa, iBa};
     for (int k = 0; k < 3; ++k)
@@ -1135,7 +1145,7 @@ std::vector<TgChoice> tune_candidates(const TgLayer& L, int nimg) {
   for (int cfg : cfgs) {
     const TgShape sh = tg_shape(cfg);
     const long long tiles = (long long)((M + sh.bm - 1) / sh.bm) * ((L.Cout + sh.bn - 1) / sh.bn);
-    for (int ms : {0, 8, 16, 32, 64, 128, 256}) {
+    for (int ms : {0, 4, 8, 16, 32, 64, 128, 256}) {
       if (ms > 0 && ms >= max_ksteps) continue;  // would not split anything
       if (ms > 0) {
         long long slabs = 0;
@@ -1353,7 +1363,10 @@ int run_decoder_backward(ian_handle* h, int mode, int c1, int r1, int c2, int r2
     HIPCHK(h, hipMalloc((void**)&h->d_gseed, (size_t)3 * H * W * sizeof(float)));
     ++h->alloc_epoch;
   }
-  if (d_patch) HIPCHK(h, launch_patch_seed_dev(out.d, d_rgb, h->d_gseed, H, W, d_patch, mode, st));
+  // interactive loop + image-producing deconv (IAN_simple): seed, tanh' and the first backward-data in one launch
+  const bool fused_seed = d_patch && last.d.kind == IAN_OP_DECONV5S2 && last.edge;
+  if (fused_seed) {
+  } else if (d_patch) HIPCHK(h, launch_patch_seed_dev(out.d, d_rgb, h->d_gseed, H, W, d_patch, mode, st));
   else HIPCHK(h, launch_patch_seed(out.d, d_rgb, h->d_gseed, H, W, c1, r1, c2, r2, mode, st));  // dL/dX_hat, NCHW
 
   std::vector<char> touched(nslots, 0);
@@ -1403,11 +1416,16 @@ int run_decoder_backward(ian_handle* h, int mode, int c1, int r1, int c2, int r2
       Slot& in = h->slots[op.d.src];
       if (touched[op.d.src]) return fail(h, -9, "imgrad: '%s' input has several consumers", op.name.c_str());
       if ((rc = ensure_slot(h, op.d.src, 1, true))) return rc;
-      HIPCHK(h, launch_dact_nchw(h->d_gseed, out.d, op.d_scale, 1, out.c, H * W, op.d.act, st));
       ProducerEpi e = epi_of(op.d.src);
       if (e.scale_period) return fail(h, -9, "imgrad: per-feature batch-norm directly under the image deconv");
-      HIPCHK(h, launch_deconv_out_bwd(h->d_gseed, op.d_edge_w, in.g, e.yfwd, e.scale, 1, op.d.in_h, op.d.in_w, in.cs,
-                                      op.d.cout, e.act, st));
+      if (fused_seed) {
+        HIPCHK(h, launch_deconv_out_bwd_seed(out.d, d_rgb, d_patch, mode, op.d.act, op.d_scale, op.d_edge_w, in.g, e.yfwd, e.scale,
+                                             op.d.in_h, op.d.in_w, in.cs, op.d.cout, e.act, st));
+      } else {
+        HIPCHK(h, launch_dact_nchw(h->d_gseed, out.d, op.d_scale, 1, out.c, H * W, op.d.act, st));
+        HIPCHK(h, launch_deconv_out_bwd(h->d_gseed, op.d_edge_w, in.g, e.yfwd, e.scale, 1, op.d.in_h, op.d.in_w, in.cs,
+                                        op.d.cout, e.act, st));
+      }
       touched[op.d.src] = 1;
       continue;
     }
@@ -1555,8 +1573,8 @@ int decode_one_graph(ian_handle* h, const float* z) {
   hipStream_t st = h->edit_stream;
   rc = run_or_replay(h, h->g_fwd, [&]() -> int {
     Slot& zs = h->slots[h->desc.z_slot];
-    HIPCHK(h, hipMemcpyAsync(h->d_stage_in, h->pin + PIN_Z, zl * sizeof(float), hipMemcpyHostToDevice, st));
-    HIPCHK(h, launch_rows_copy(h->d_stage_in, zs.c, zs.d, zs.cs, 1, zs.c, st));
+    // one row: straight into the slot (its channel padding beyond num_latents stays zero), no staging kernel
+    HIPCHK(h, hipMemcpyAsync(zs.d, h->pin + PIN_Z, zl * sizeof(float), hipMemcpyHostToDevice, st));
     return run_segment(h, IAN_SEG_DEC, 1, st);
   });
   if (rc) return rc;
@@ -1625,8 +1643,7 @@ int grad_common(ian_handle* h, int mode, int c1, int r1, int c2, int r2, const f
       HIPCHK(h, hipMemcpyAsync(h->d_patch, patch, 4 * sizeof(int), hipMemcpyHostToDevice, st));
       int r = run_decoder_backward(h, mode, 0, 0, out.w, out.h, d_rgb, st, h->d_patch);
       if (r) return r;
-      HIPCHK(h, launch_rows_copy(zs.g, zs.cs, h->d_stage_out, zs.c, 1, zs.c, st));
-      HIPCHK(h, hipMemcpyAsync(h->pin + PIN_DZ, h->d_stage_out, zs.c * sizeof(float), hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipMemcpyAsync(h->pin + PIN_DZ, zs.g, zs.c * sizeof(float), hipMemcpyDeviceToHost, st));
       return 0;
     });
     if (rc) return rc;

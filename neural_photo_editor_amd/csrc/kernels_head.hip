@@ -43,6 +43,7 @@ constexpr int HD_NF = 6;          // fused filters
 constexpr int HD_YS = 230;        // LDS row stride of Y: >= 224 and = 6 mod 32 -> the shift-add reads are conflict-free
 constexpr int HD_RING = 16;       // open output rows (power of two >= 9)
 constexpr int HD_MAXT = 37;       // taps: 37 * 6 = 222 <= 224 columns
+constexpr int HD_SLOTS = 44;      // shift-add slots: 12 for dy = 0, 4 for each dy in -4..-1, 1..4
 
 template <int NTILES>  // N tiles of 32 columns actually holding (tap,filter) pairs: ceil(ntaps*6/32) <= 7
 __global__ __launch_bounds__(512, 2) void head6_kernel(HeadFusedArgs a) {
@@ -78,9 +79,9 @@ __global__ __launch_bounds__(512, 2) void head6_kernel(HeadFusedArgs a) {
     }
   }
   for (int i = tid; i < HD_RING * HD_W * HD_NF; i += 512) ring[i] = 0.f;
-  int tap_e[HD_MAXT];   // (dy + 4) | (dx + 64) << 8 of every tap: wave-uniform, kept in (scalar) registers for the whole kernel
+  int slot_e[HD_SLOTS];   // tap id | (dx + 64) << 8, or -1: wave-uniform, kept in scalar registers for the whole kernel
 #pragma unroll
-  for (int t = 0; t < HD_MAXT; ++t) tap_e[t] = (t < a.ntaps) ? a.itab[t] : 0;
+  for (int t = 0; t < HD_SLOTS; ++t) slot_e[t] = a.itab[t];
   const int f_own = tid % HD_NF;
   const float sc_f = a.ftab[f_own], sh_f = a.ftab[8 + f_own];
   const int act_f = (int)a.ftab[16 + f_own];
@@ -152,23 +153,34 @@ __global__ __launch_bounds__(512, 2) void head6_kernel(HeadFusedArgs a) {
     }
     if (r + 1 < r_end) HD_STORE_ROW(buf ^ 1);  // the other buffer: nobody reads it during this row
     __syncthreads();
-    // ---- shift-add: out[y = r - dy_t][x - dx_t][f] += Y[x][(t,f)], gathered: thread (x,f) owns output column x, filter f
-    // of every open row.  Its 33 reads of Y are independent (issued back to back), each lands in the ring through a
-    // fire-and-forget ds_add_f32 on an address only this thread touches -- LDS operations of a wave execute in order, so the
-    // summation order is the tap order: deterministic, and no read-modify-write latency chain.
+    // ---- shift-add: out[y = r - dy][x][f] += sum over the taps with that dy of Y[x + dx][(t,f)].  Thread (x,f) owns its
+    // ring column for the whole kernel.  The taps arrive grouped by dy in a STATIC slot layout (12 slots for dy = 0, 4 for
+    // every other dy, empty = -1; wave-uniform, held in scalar registers), so the whole walk is straight-line code: all
+    // reads of Y are issued back to back (no table-lookup -> load latency chains: the first version of this loop spent as
+    // long here as in the MFMAs), the nine per-dy sums live in registers, and the order of additions is fixed.
     if (tid < HD_W * HD_NF) {
       const int f = tid % HD_NF, x = tid / HD_NF;
-      float* my_ring = ring + x * HD_NF + f;
       const float* my_y = Ys + f;
+      float sd[9];
 #pragma unroll
-      for (int t = 0; t < HD_MAXT; ++t) {
-        if (t < a.ntaps) {                                   // uniform
-          const int y = r - ((tap_e[t] & 0xFF) - 4);         // uniform
-          if (y >= y0 && y < y1) {
-            const int xx = x + ((tap_e[t] >> 8) - 64);
-            if ((unsigned)xx < (unsigned)HD_W) atomicAdd(my_ring + (y & (HD_RING - 1)) * HD_W * HD_NF, my_y[xx * HD_YS + t * HD_NF]);
-          }
+      for (int g = 0; g < 9; ++g) {
+        const int s0 = (g == 0) ? 0 : 12 + (g - 1) * 4, cnt = (g == 0) ? 12 : 4;
+        float acc_g = 0.f;
+#pragma unroll
+        for (int q = 0; q < cnt; ++q) {
+          const int e = slot_e[s0 + q];
+          const int xx = x + (((e >> 8) & 0xFF) - 64);
+          const bool ok = (e >= 0) && ((unsigned)xx < (unsigned)HD_W);
+          const float v = my_y[min(max(xx, 0), HD_W - 1) * HD_YS + (e & 0xFF) * HD_NF];   // always a valid address
+          acc_g += ok ? v : 0.f;
         }
+        sd[g] = acc_g;
+      }
+#pragma unroll
+      for (int g = 0; g < 9; ++g) {
+        const int dy = (g == 0) ? 0 : (g <= 4 ? g - 5 : g - 4);
+        const int y = r - dy;
+        if (y >= y0 && y < y1) ring[((y & (HD_RING - 1)) * HD_W + x) * HD_NF + f] += sd[g];   // uniform branch
       }
       // output rows no later input row can reach are complete: y = r - halo, and everything still open after the
       // image's last row

@@ -339,6 +339,56 @@ __global__ __launch_bounds__(256) void deconv_out_bwd_kernel(const float* __rest
   dx[idx] = acc * d * (scale ? scale[ci] : 1.f);
 }
 
+// The latent brush's first backward step in ONE launch (batch 1): loss seed (API.py:59,64) on the brush rectangle, the
+// output activation's derivative and the backward-data of the image-producing transposed conv.  The seed is non-zero
+// only inside the rectangle, so a thread visits only the taps whose output pixel lies in it (most threads: none).
+//   gout[co,oy,ox] = seed(co,oy,ox) * act'(xhat) * oscale[co];   dx[iy,ix,ci] = (sum_{taps in patch} gout * w) * act_in'(yfwd) * scale[ci]
+__global__ __launch_bounds__(256) void deconv_out_bwd_seed_kernel(const float* __restrict__ xhat, const float* __restrict__ rgb,
+                                                                  const int* __restrict__ patch, int mode, int out_act,
+                                                                  const float* __restrict__ oscale, const float* __restrict__ w,
+                                                                  float* __restrict__ dx, const float* __restrict__ yfwd,
+                                                                  const float* __restrict__ scale, int H, int W, int Cin,
+                                                                  int Cout, int act) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= H * W * Cin) return;
+  const int ci = idx % Cin, pix = idx / Cin;
+  const int ix = pix % W, iy = pix / W;
+  const int OH = 2 * H, OW = 2 * W;
+  const int c1 = patch[0], r1 = patch[1], c2 = patch[2], r2 = patch[3];
+  const int cnt = 3 * (r2 - r1) * (c2 - c1);
+  float acc = 0.f;
+  if (cnt > 0) {
+    const float inv = 1.f / (float)cnt;
+    const int ky0 = max(0, r1 - (2 * iy - 2)), ky1 = min(5, r2 - (2 * iy - 2));
+    const int kx0 = max(0, c1 - (2 * ix - 2)), kx1 = min(5, c2 - (2 * ix - 2));
+    for (int ky = ky0; ky < ky1; ++ky) {
+      const int oy = 2 * iy - 2 + ky;
+      if ((unsigned)oy >= (unsigned)OH) continue;
+      for (int kx = kx0; kx < kx1; ++kx) {
+        const int ox = 2 * ix - 2 + kx;
+        if ((unsigned)ox >= (unsigned)OW) continue;
+        for (int co = 0; co < Cout; ++co) {
+          const int o = (co * OH + oy) * OW + ox;
+          const float xh = xhat[o];
+          float gv = (mode == 0) ? inv : 2.f * (xh - rgb[o]) * inv;
+          gv = gv * m_dact(xh, out_act) * (oscale ? oscale[co] : 1.f);
+          acc = fmaf(gv, w[((size_t)(ky * 5 + kx) * 4 + co) * Cin + ci], acc);
+        }
+      }
+    }
+  }
+  const float d = yfwd ? m_dact(yfwd[idx], act) : 1.f;
+  dx[idx] = acc * d * (scale ? scale[ci] : 1.f);
+}
+hipError_t launch_deconv_out_bwd_seed(const float* xhat, const float* rgb, const int* patch, int mode, int out_act,
+                                      const float* oscale, const float* w, float* dx, const float* yfwd, const float* scale, int H,
+                                      int W, int Cin, int Cout, int act, hipStream_t s) {
+  const int total = H * W * Cin;
+  hipLaunchKernelGGL(deconv_out_bwd_seed_kernel, dim3((total + 255) / 256), dim3(256), 0, s, xhat, rgb, patch, mode, out_act, oscale,
+                     w, dx, yfwd, scale, H, W, Cin, Cout, act);
+  return hipGetLastError();
+}
+
 hipError_t launch_deconv_out_bwd(const float* g, const float* w, float* dx, const float* yfwd, const float* scale,
                                  int n, int H, int W, int Cin, int Cout, int act, hipStream_t s) {
   const size_t total = (size_t)n * H * W * Cin;

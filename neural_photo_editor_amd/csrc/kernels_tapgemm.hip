@@ -358,36 +358,61 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
   tg_store<BM, BN, WM, WN>(p, it, cl, acc, wm, wn, lane);
 }
 
-// split-K second pass: y = epilogue(sum of slabs).  Block = (tile, group of RPI rows); float4 along channels.
-template <int BM, int BN>
+// split-K second pass: y = epilogue(sum of slabs).  Block = (tile, group of rows); float4 along channels; KP lanes share
+// one output element's slabs (contiguous chunks of the split index, combined in lane order through LDS): at batch 1 a
+// tile has tens of slabs and few tiles exist, so the pass is a latency chain unless the slab loads run in parallel.
+// The summation order is fixed for a given KP (chunk sums in order, then chunks in order): reproducible.
+template <int BM, int BN, int KP>
 __device__ __forceinline__ void tg_reduce_body(const TgReduceParams& p) {
-  constexpr int CG = BN / 4;     // float4 groups per row
-  constexpr int RPI = 256 / CG;  // rows per block
-  constexpr int RG = BM / RPI;   // row groups per tile
+  constexpr int CG = BN / 4;            // float4 groups per row
+  constexpr int RPI = 256 / (CG * KP);  // rows per block
+  constexpr int RG = BM / RPI;          // row groups per tile
+  __shared__ float4 part[KP > 1 ? 256 : 1];
   const TgTile t = p.tiles[blockIdx.x / RG];
   const TgClass cl = p.classes[t.cls];
-  const int cg = threadIdx.x % CG;
-  const int row = (blockIdx.x % RG) * RPI + threadIdx.x / CG;
+  const int kp = threadIdx.x / (CG * RPI);
+  const int rem_t = threadIdx.x % (CG * RPI);
+  const int cg = rem_t % CG;
+  const int row = (blockIdx.x % RG) * RPI + rem_t / CG;
   const int qhw_mask = (1 << p.qhw_shift) - 1, qw_mask = (1 << p.qw_shift) - 1;
   const int m = t.m0 + row;
-  if (m >= p.M) return;
-  const float* base = p.slab + (size_t)t.slab0 * (BM * BN) + row * BN + cg * 4;
-  float4 s = *reinterpret_cast<const float4*>(base);
-  int k = 1;
-  for (; k + 3 < t.nsplit; k += 4) {  // 4 independent loads in flight
-    const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)(k + 0) * (BM * BN));
-    const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)(k + 1) * (BM * BN));
-    const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)(k + 2) * (BM * BN));
-    const float4 v3 = *reinterpret_cast<const float4*>(base + (size_t)(k + 3) * (BM * BN));
-    s.x = (((s.x + v0.x) + v1.x) + v2.x) + v3.x;
-    s.y = (((s.y + v0.y) + v1.y) + v2.y) + v3.y;
-    s.z = (((s.z + v0.z) + v1.z) + v2.z) + v3.z;
-    s.w = (((s.w + v0.w) + v1.w) + v2.w) + v3.w;
+  const bool live = m < p.M;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    const int per = (t.nsplit + KP - 1) / KP;
+    const int k0 = kp * per, k1 = min(t.nsplit, k0 + per);
+    const float* base = p.slab + (size_t)t.slab0 * (BM * BN) + row * BN + cg * 4;
+    int k = k0;
+    if (k < k1) {
+      s = *reinterpret_cast<const float4*>(base + (size_t)k * (BM * BN));
+      ++k;
+    }
+    for (; k + 3 < k1; k += 4) {  // 4 independent loads in flight
+      const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)(k + 0) * (BM * BN));
+      const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)(k + 1) * (BM * BN));
+      const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)(k + 2) * (BM * BN));
+      const float4 v3 = *reinterpret_cast<const float4*>(base + (size_t)(k + 3) * (BM * BN));
+      s.x = (((s.x + v0.x) + v1.x) + v2.x) + v3.x;
+      s.y = (((s.y + v0.y) + v1.y) + v2.y) + v3.y;
+      s.z = (((s.z + v0.z) + v1.z) + v2.z) + v3.z;
+      s.w = (((s.w + v0.w) + v1.w) + v2.w) + v3.w;
+    }
+    for (; k < k1; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (size_t)k * (BM * BN));
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
-  for (; k < t.nsplit; ++k) {
-    const float4 v = *reinterpret_cast<const float4*>(base + (size_t)k * (BM * BN));
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  if (KP > 1) {
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (kp != 0) return;
+#pragma unroll
+    for (int q = 1; q < KP; ++q) {
+      const float4 v = part[threadIdx.x + q * CG * RPI];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
+  if (!live) return;
   const int n = m >> p.qhw_shift;
   const int rem = m & qhw_mask;
   const int oy = (rem >> p.qw_shift) * p.so + cl.py, ox = (rem & qw_mask) * p.so + cl.px;
@@ -408,9 +433,9 @@ __device__ __forceinline__ void tg_reduce_body(const TgReduceParams& p) {
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int KP>
 __global__ __launch_bounds__(256) void tapgemm_reduce_kernel(const TgReduceParams p) {
-  tg_reduce_body<BM, BN>(p);
+  tg_reduce_body<BM, BN, KP>(p);
 }
 
 template <int BM, int BN, int WM, int WN, int VAR>
@@ -451,21 +476,26 @@ hipError_t launch_tapgemm(int cfg, const TgParams& p, int nitems, hipStream_t s)
 }
 
 template <int BM, int BN>
-static hipError_t launch_red(const TgReduceParams& p, int ntiles, hipStream_t s) {
-  constexpr int RG = BM / (256 / (BN / 4));
-  hipLaunchKernelGGL((tapgemm_reduce_kernel<BM, BN>), dim3(ntiles * RG), dim3(256), 0, s, p);
+static hipError_t launch_red(const TgReduceParams& p, int ntiles, int kp, hipStream_t s) {
+  if (kp > 1) {
+    constexpr int RG = BM / (256 / (BN / 4 * 4));
+    hipLaunchKernelGGL((tapgemm_reduce_kernel<BM, BN, 4>), dim3(ntiles * RG), dim3(256), 0, s, p);
+  } else {
+    constexpr int RG = BM / (256 / (BN / 4));
+    hipLaunchKernelGGL((tapgemm_reduce_kernel<BM, BN, 1>), dim3(ntiles * RG), dim3(256), 0, s, p);
+  }
   return hipGetLastError();
 }
 
-hipError_t launch_tapgemm_reduce(int cfg, const TgReduceParams& p, int ntiles, hipStream_t s) {
+hipError_t launch_tapgemm_reduce(int cfg, const TgReduceParams& p, int ntiles, int kp, hipStream_t s) {
   if (ntiles <= 0) return hipSuccess;
   switch (cfg) {
-    case TG_128x128: return launch_red<128, 128>(p, ntiles, s);
-    case TG_128x64: return launch_red<128, 64>(p, ntiles, s);
-    case TG_64x64: return launch_red<64, 64>(p, ntiles, s);
-    case TG_32x128: return launch_red<32, 128>(p, ntiles, s);
-    case TG_256x128: return launch_red<256, 128>(p, ntiles, s);
-    case TG_128x32: return launch_red<128, 32>(p, ntiles, s);
+    case TG_128x128: return launch_red<128, 128>(p, ntiles, kp, s);
+    case TG_128x64: return launch_red<128, 64>(p, ntiles, kp, s);
+    case TG_64x64: return launch_red<64, 64>(p, ntiles, kp, s);
+    case TG_32x128: return launch_red<32, 128>(p, ntiles, kp, s);
+    case TG_256x128: return launch_red<256, 128>(p, ntiles, kp, s);
+    case TG_128x32: return launch_red<128, 32>(p, ntiles, kp, s);
   }
   return hipErrorInvalidValue;
 }
