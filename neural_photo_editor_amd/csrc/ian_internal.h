@@ -195,6 +195,17 @@ struct HeadTailArgs {
 };
 hipError_t launch_head_tail(const HeadTailArgs& a, int n, hipStream_t s);
 
+// dec_out of IAN_simple on the matrix cores (kernels_head.hip): x NHWC [n][H][32][128] -> y NCHW [n][Cout][2H][64]
+struct DeconvSmallArgs {
+  const float* x;
+  const float* w;      // edge packing [25 (ky,kx)][4][128]
+  const float* scale;  // per output channel or nullptr
+  const float* shift;
+  float* y;
+  int H, W, xs, bands, act;
+};
+hipError_t launch_deconv_small(const DeconvSmallArgs& a, int n, int Cout, hipStream_t s);
+
 // NPE.paint's photo blend and the uint8 image conversion on the device (kernels_npe.hip; NPE.py:218-231, 110, 261)
 struct PhotoBlendArgs {
   const float* xhat;           // decoder output, NCHW [3][64][64]

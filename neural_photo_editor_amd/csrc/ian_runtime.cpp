@@ -112,6 +112,7 @@ struct Options {
   int tg_nosplit_min_out = 1 << 30;  // outputs (M*Cout) above which 64x64 is forced even if it under-fills
   int mdc_head = 2;                  // few-filter MDCL layers: 0 = tapgemm, 1 = VALU head kernel, 2 = + sibling layers fused
   int tg_variant = 2;                // K-loop schedule of tapgemm_kernel (kernels_tapgemm.hip); autotune picks per layer
+  int dec_out_mfma = 1;              // image-producing deconv (IAN_simple dec_out) on the matrix cores for batches >= 4
   int edit_graph = 1;                // batch-1 host-pointer calls (the NPE edit loop) replay captured hipGraphs
   int head_fused = 1;                // RGB-Beta head as head6 + head_tail (kernels_head.hip) when the graph matches IAN.py:183-207
   int head_fused_min_n = 8;          // ... for batches of at least this many images (the latent brush's batch-1 backward
@@ -1063,6 +1064,18 @@ int run_op_fwd(ian_handle* h, OpPlan& op, int n, hipStream_t st) {
       }
       return run_tapgemm(h, op.fwd, n, src.d, dst.d, dst.cs, fwd_epi(op, nullptr), st);
     case IAN_OP_DECONV5S2:
+      if (op.edge && h->opt.dec_out_mfma && n >= 4 && op.d.cin == 128 && src.cs == 128 && op.d.in_w == 32 && (op.d.in_h % 2) == 0 &&
+          (op.d.cout == 3 || op.d.cout == 4)) {
+        // image-producing deconv on the matrix cores (kernels_head.hip: contract first, scatter the 25 taps later)
+        DeconvSmallArgs a;
+        a.x = src.d; a.w = op.d_edge_w; a.scale = op.d_scale; a.shift = op.d_shift; a.y = dst.d;
+        a.H = op.d.in_h; a.W = op.d.in_w; a.xs = src.cs; a.act = op.d.act;
+        int bands = 1;
+        while (n * bands < 256 && bands < 8 && (op.d.in_h % (4 * bands)) == 0) bands *= 2;   // 2 halo row pairs per band
+        a.bands = bands;
+        HIPCHK(h, launch_deconv_small(a, n, op.d.cout, st));
+        return 0;
+      }
       if (op.edge) {
         HIPCHK(h, launch_deconv_out_nchw(src.d, op.d_edge_w, op.d_scale, op.d_shift, dst.d, n, op.d.in_h, op.d.in_w,
                                          src.cs, op.d.cout, op.d.act, st));
@@ -2146,6 +2159,7 @@ int ian_set_option(ian_handle* h, const char* key, int32_t value) {
   else if (k == "mdc_head") h->opt.mdc_head = value;
   else if (k == "head_fused") h->opt.head_fused = value;
   else if (k == "edit_graph") h->opt.edit_graph = value;
+  else if (k == "dec_out_mfma") h->opt.dec_out_mfma = value;
   else if (k == "head_fused_min_n") h->opt.head_fused_min_n = std::max(1, value);
   else return fail(h, -1, "unknown option '%s'", key);
   for (auto& op : h->ops) {  // schedules depend on the options

@@ -307,4 +307,171 @@ hipError_t launch_head_tail(const HeadTailArgs& a, int n, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// dec_out of IAN_simple (IAN_simple.py:171-181): 5x5 stride-2 transposed conv 128 -> Cout <= 4 channels + tanh, NHWC in,
+// NCHW image out -- the same "contract first, shift later" scheme as head6_kernel:
+//     Y[q][(k,co)] = sum_c x[q][c] * W[k][co][c]            one dense 128 -> 25*Cout contraction per INPUT pixel (fp32 MFMA)
+//     out[2q - 2 + k][co] += Y[q][(k,co)]                    the 25 taps scatter into the four output parities
+// Round 1's VALU kernel ran at 11 % of the HBM roof (41 us at batch 64: LDS-issue bound, 16 workgroups per image tile).
+// A workgroup walks pairs of input rows (M = 2 x 32 pixels); thread (co, ox) owns an output column of every open output row
+// and gathers its taps from Y in straight-line code: for the row pair (r, r+1) the touched output rows are 2r-2 .. 2r+4, all
+// indices static.  Output rows 2r, 2r+1 are complete after the pair and leave through the affine + activation epilogue.
+// ------------------------------------------------------------------------------------------------
+constexpr int DS_W = 32;            // input width; M per step = 2 rows x 32 pixels
+constexpr int DS_RING = 8;
+
+template <int COUT>
+__global__ __launch_bounds__(512, 2) void deconv_small_kernel(DeconvSmallArgs a) {
+  constexpr int N = 25 * COUT;
+  constexpr int NTILES = (N + 31) / 32;          // 3 for Cout = 3, 4 for Cout = 4
+  constexpr int YS = NTILES * 32 + 2;            // = 2 mod 32: even / odd output columns read disjoint bank parities
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Xs = sm;                                // [64][132]   (single buffer: refilled between the barriers)
+  float* Ys = Xs + 64 * HD_XS;                   // [64][YS]
+  float* ring = Ys + 64 * YS;                    // [8][COUT][64]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wg = wave >> 1;
+  const int band = blockIdx.x % a.bands, img = blockIdx.x / a.bands;
+  const int rows_per_band = a.H / a.bands;       // input rows per band (even)
+  const int q0 = band * rows_per_band, q1 = q0 + rows_per_band;
+  const int oy_lo = 2 * q0, oy_hi = 2 * q1;      // owned output rows
+  const int r_begin = max(0, q0 - 2), r_end = min(a.H, q1 + 2);   // row pairs (even aligned) that reach them
+
+  float wreg[64];
+  {
+    const int j = wg * 32 + (lane & 31);
+    const bool ok = (wg < NTILES) && (j < N);
+    const int k = ok ? j / COUT : 0, co = ok ? j % COUT : 0;
+    const float* wp = a.w + ((size_t)k * 4 + co) * HD_CIN + (lane >> 5) * 4;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4*>(wp + kk * 8);
+      wreg[kk * 4 + 0] = v.x; wreg[kk * 4 + 1] = v.y; wreg[kk * 4 + 2] = v.z; wreg[kk * 4 + 3] = v.w;
+    }
+  }
+  for (int i = tid; i < DS_RING * COUT * 64; i += 512) ring[i] = 0.f;
+
+  const float* xin = a.x + (size_t)img * a.H * DS_W * a.xs;
+  float4 st0, st1, st2, st3;
+  const int s_px = tid >> 5, s_c4 = (tid & 31) * 4;   // pixel s_px + 16*q of the 64-pixel row pair (contiguous in memory)
+#define DS_LOAD(r)                                                                   \
+  {                                                                                  \
+    const float* rp_ = xin + ((size_t)(r) * DS_W + s_px) * a.xs + s_c4;              \
+    st0 = *reinterpret_cast<const float4*>(rp_);                                     \
+    st1 = *reinterpret_cast<const float4*>(rp_ + (size_t)16 * a.xs);                 \
+    st2 = *reinterpret_cast<const float4*>(rp_ + (size_t)32 * a.xs);                 \
+    st3 = *reinterpret_cast<const float4*>(rp_ + (size_t)48 * a.xs);                 \
+  }
+#define DS_STORE()                                                                   \
+  {                                                                                  \
+    float* sp_ = Xs + s_px * HD_XS + s_c4;                                           \
+    *reinterpret_cast<float4*>(sp_) = st0;                                           \
+    *reinterpret_cast<float4*>(sp_ + 16 * HD_XS) = st1;                              \
+    *reinterpret_cast<float4*>(sp_ + 32 * HD_XS) = st2;                              \
+    *reinterpret_cast<float4*>(sp_ + 48 * HD_XS) = st3;                              \
+  }
+  DS_LOAD(r_begin);
+  DS_STORE();
+  __syncthreads();
+
+  const float* a_base = Xs + (wm * 32 + (lane & 31)) * HD_XS + (lane >> 5) * 4;
+  const int col_l = lane & 31, rhalf = 4 * (lane >> 5);
+  const int OH = 2 * a.H, OW = 2 * DS_W;
+  // owner thread: (co, ox); consecutive threads = consecutive ox (coalesced NCHW stores)
+  const bool owner = tid < COUT * 64;
+  const int o_co = owner ? tid >> 6 : 0, o_ox = tid & 63;
+  const float sc = (owner && a.scale) ? a.scale[o_co] : 1.f, sh = (owner && a.shift) ? a.shift[o_co] : 0.f;
+  const int par = o_ox & 1;                      // taps with kx = par, par + 2 (, 4)
+  float* my_ring = ring + o_co * 64 + o_ox;      // + slot * COUT * 64
+  float* outp = a.y + ((size_t)img * COUT + o_co) * OH * OW + o_ox;
+
+  for (int r = r_begin; r < r_end; r += 2) {
+    if (r + 2 < r_end) DS_LOAD(r + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wg < NTILES) {
+      hd_f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const float4 av = *reinterpret_cast<const float4*>(a_base + kk * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wreg[kk * 4 + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wreg[kk * 4 + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wreg[kk * 4 + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wreg[kk * 4 + 3], acc, 0, 0, 0);
+      }
+      const int jcol = wg * 32 + col_l;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int px = wm * 32 + (e & 3) + 8 * (e >> 2) + rhalf;
+        Ys[px * YS + jcol] = acc[e];
+      }
+    }
+    __syncthreads();                             // Y complete; every wave is done reading Xs
+    if (r + 2 < r_end) DS_STORE();
+    if (owner) {
+      // taps of this thread's column parity: kx = par + 2*i, source column qx = (ox + 2 - kx) / 2 = (ox - par)/2 + 1 - i
+      const int qxb = ((o_ox - par) >> 1) + 1;
+      float s7[7];
+#pragma unroll
+      for (int d = 0; d < 7; ++d) s7[d] = 0.f;
+#pragma unroll
+      for (int ql = 0; ql < 2; ++ql)             // input row r + ql
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) {         // output row 2(r+ql) - 2 + ky = (2r - 2) + (2ql + ky)
+          float s = 0.f;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int kx = par + 2 * i;          // i = 2 exists for even columns only (kx = 4)
+            const int qx = qxb - i;
+            const bool ok = (kx < 5) && ((unsigned)qx < (unsigned)DS_W);
+            const float v = Ys[(ql * DS_W + min(max(qx, 0), DS_W - 1)) * YS + (ky * 5 + min(kx, 4)) * COUT + o_co];
+            s += ok ? v : 0.f;
+          }
+          s7[2 * ql + ky] += s;
+        }
+#pragma unroll
+      for (int d = 0; d < 7; ++d) {
+        const int oy = 2 * r - 2 + d;            // uniform
+        if (oy >= oy_lo && oy < oy_hi) my_ring[(oy & (DS_RING - 1)) * COUT * 64] += s7[d];
+      }
+      // with input rows <= r+1 done, output rows <= 2r+1 are complete (even rows take their last tap from row oy/2 + 1):
+      // 2r-2 .. 2r+1 are new; after the image's last pair also 2r+2, 2r+3
+      const int f_lo = max(oy_lo, 2 * r - 2), f_hi = min(oy_hi - 1, (r + 2 >= a.H) ? 2 * r + 3 : 2 * r + 1);
+      for (int oy = f_lo; oy <= f_hi; ++oy) {
+        float* rp = my_ring + (oy & (DS_RING - 1)) * COUT * 64;
+        outp[(size_t)oy * OW] = hd_act(*rp * sc + sh, a.act);
+        *rp = 0.f;
+      }
+    }
+    __syncthreads();                             // Xs refilled, Ys free
+  }
+#undef DS_LOAD
+#undef DS_STORE
+}
+
+hipError_t launch_deconv_small(const DeconvSmallArgs& a, int n, int Cout, hipStream_t s) {
+  if (a.W != DS_W || (a.H & 1) || a.bands < 1 || (a.H % (2 * a.bands)) || a.xs < HD_CIN || Cout < 3 || Cout > 4) return hipErrorInvalidValue;
+  const int ntiles = (25 * Cout + 31) / 32, ys = ntiles * 32 + 2;
+  const size_t lds = (size_t)(64 * HD_XS + 64 * ys + DS_RING * Cout * 64) * sizeof(float);
+#define DS_LAUNCH(CO)                                                                                             \
+  {                                                                                                               \
+    static bool attr = false;                                                                                     \
+    auto k = deconv_small_kernel<CO>;                                                                             \
+    if (!attr) {                                                                                                  \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return e;                                                                              \
+      attr = true;                                                                                                \
+    }                                                                                                             \
+    hipLaunchKernelGGL(k, dim3(n * a.bands), dim3(512), lds, s, a);                                               \
+    return hipGetLastError();                                                                                     \
+  }
+  if (Cout == 3) DS_LAUNCH(3)
+  DS_LAUNCH(4)
+#undef DS_LAUNCH
+}
+
 }  // namespace ian
