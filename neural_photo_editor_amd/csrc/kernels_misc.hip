@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void conv1_nchw_kernel(const float* __restrict
 // de-interleaved by column parity (even columns, then odd columns): the stride-2 gather "column 2*ox + kx" of the 32
 // lanes becomes a contiguous read (round 1 measured 47.6 % bank-conflict cycles on the interleaved image).
 typedef float c1_f32x16 __attribute__((ext_vector_type(16)));
-constexpr int C1M_ROWS = 4;
+constexpr int C1M_ROWS = 2;   // 4 rows per block measured slower (34 vs 23 us at batch 64): fewer, longer latency chains
 template <int COUT>
 __global__ __launch_bounds__(256) void conv1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ scale,

@@ -276,6 +276,7 @@ class Trainer:
         self._build_params(params)
         self._build_layers(deconv_flip)
         self._alloc()
+        self._dirty = {"enc", "Z", "dec"}
         self._plans, self._works, self._fired, self._buckets = {}, [], set(), None
         self._ev, self._evlog, self.overlap_log = 0, [], []
         self.overlap = True                      # data parallel: all-reduce gradient buckets while backward still runs
@@ -382,16 +383,30 @@ class Trainer:
     # parameter refresh (after every optimiser update): reference layout -> kernel layouts
     # ---------------------------------------------------------------------------------------------
     def refresh_weights(self):
+        """Repack (device-side gather) the layers whose parameters changed since the last call: update_gen moves
+        decoder_params + Z_params, update_discrim encoder_params + Z_params (train_IAN.py:274-276), so each step needs
+        to repack about half of the weights, not all of them."""
         k = self.k
+        dirty = self._dirty
+        if not dirty:
+            return
         for name, (layer, pnames) in self.layers.items():
-            if pnames is None:
+            if pnames is None or self.where[pnames[0]] not in dirty:
                 continue
             layer.set_params([self.P(n) for n in pnames])
-        k.mb_weight(self.P("minibatch_discrim.theta"), self.P("minibatch_discrim.log_weight_scale"), self.mb_W, self.mb_colscale,
-                    1024, 2500)
-        self.layers["mb"][0].set_params([self.mb_W])
-        self.fc2_bias = self.torch.empty(8192, dtype=self.torch.float32, device=self.dev)
-        k.gather(self.P("l_dec_fc2.b"), self.fc2_perm, self.fc2_bias, 8192)
+        if "enc" in dirty:
+            k.mb_weight(self.P("minibatch_discrim.theta"), self.P("minibatch_discrim.log_weight_scale"), self.mb_W, self.mb_colscale,
+                        1024, 2500)
+            self.layers["mb"][0].set_params([self.mb_W])
+        if "dec" in dirty:
+            if not hasattr(self, "fc2_bias"):
+                self.fc2_bias = self.torch.empty(8192, dtype=self.torch.float32, device=self.dev)
+            k.gather(self.P("l_dec_fc2.b"), self.fc2_perm, self.fc2_bias, 8192)
+        self._dirty = set()
+
+    def mark_params_changed(self, *groups):
+        """Call after writing parameter values behind the trainer's back (tests, checkpoint loading)."""
+        self._dirty.update(groups or ("enc", "Z", "dec"))
 
     # ---------------------------------------------------------------------------------------------
     # building blocks
@@ -805,6 +820,7 @@ class Trainer:
         b1, b2 = float(self.cfg["beta1"]), 0.999
         a_t = self.lr * math.sqrt(1.0 - b2 ** g.t) / (1.0 - b1 ** g.t)
         self.k.adam(g.p, g.g, g.m, g.v, g.numel, a_t, b1, b2, 1e-8)
+        self._dirty.add(gname)
 
     # ---------------------------------------------------------------------------------------------
     # gradient all-reduce overlapped with backward

@@ -7,10 +7,10 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 export IAN_TUNE_CACHE=$PWD/$OUT/tune.txt   # first (un-profiled) run tunes, profiled passes replay its choices
-BENCH="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-edit --no-train $*"
+BENCH="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-edit --no-train --no-full-ian $*"
 echo "$BENCH   (under rocprofv3 --kernel-trace --stats / --pmc <set>; scripts/profile_round.sh)" > $OUT/cmd.txt
 echo "== bench (full) ==" 
-timeout 600 python bench.py $* > $OUT/bench.json 2> $OUT/bench.err; tail -1 $OUT/bench.json
+if [ -z "${SKIP_FULL_BENCH:-}" ]; then timeout 600 python bench.py $* > $OUT/bench.json 2> $OUT/bench.err; tail -c 300 $OUT/bench.json; fi
 echo "== kernel trace =="
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
 ls $OUT/trace | head
