@@ -112,6 +112,7 @@ struct Options {
   int tg_nosplit_min_out = 1 << 30;  // outputs (M*Cout) above which 64x64 is forced even if it under-fills
   int mdc_head = 2;                  // few-filter MDCL layers: 0 = tapgemm, 1 = VALU head kernel, 2 = + sibling layers fused
   int tg_variant = 2;                // K-loop schedule of tapgemm_kernel (kernels_tapgemm.hip); autotune picks per layer
+  int tg_reduce_kp = 4;              // split-K reduce: lanes sharing one output element's slabs when a tile has >= 8 slabs
   int dec_out_mfma = 1;              // image-producing deconv (IAN_simple dec_out) on the matrix cores for batches >= 4
   int edit_graph = 1;                // batch-1 host-pointer calls (the NPE edit loop) replay captured hipGraphs
   int head_fused = 1;                // RGB-Beta head as head6 + head_tail (kernels_head.hip) when the graph matches IAN.py:183-207
@@ -197,6 +198,42 @@ struct ian_handle {
 };
 
 namespace {
+
+// key=value tuning knobs (ian_set_option; also read once from the environment variable IAN_OPTS="k=v,k=v" when a handle
+// or a training layer is created, so that tests and profiling runs can pin a schedule policy for every object)
+bool apply_option(Options& o, const std::string& k, int value) {
+  if (k == "tg_cfg") o.tg_cfg = value;
+  else if (k == "tg_target_items") o.tg_target_items = std::max(1, value);
+  else if (k == "tg_min_steps") o.tg_min_steps = std::max(1, value);
+  else if (k == "tg_no_split_items") o.tg_no_split_items = value;
+  else if (k == "tg_split") o.tg_split = value;
+  else if (k == "tg_xcd_group") o.tg_xcd_group = std::max(1, value);
+  else if (k == "tg_prefer_nosplit") o.tg_prefer_nosplit = value;
+  else if (k == "tg_nosplit_min_out") o.tg_nosplit_min_out = value;
+  else if (k == "tg_variant") o.tg_variant = value;
+  else if (k == "tg_reduce_kp") o.tg_reduce_kp = value;
+  else if (k == "mdc_head") o.mdc_head = value;
+  else if (k == "head_fused") o.head_fused = value;
+  else if (k == "head_fused_min_n") o.head_fused_min_n = std::max(1, value);
+  else if (k == "edit_graph") o.edit_graph = value;
+  else if (k == "dec_out_mfma") o.dec_out_mfma = value;
+  else return false;
+  return true;
+}
+void apply_env_options(Options& o) {
+  const char* env = getenv("IAN_OPTS");
+  if (!env) return;
+  std::string sv(env);
+  size_t pos = 0;
+  while (pos < sv.size()) {
+    size_t end = sv.find(',', pos);
+    if (end == std::string::npos) end = sv.size();
+    const std::string kv = sv.substr(pos, end - pos);
+    const size_t eq = kv.find('=');
+    if (eq != std::string::npos) (void)apply_option(o, kv.substr(0, eq), atoi(kv.c_str() + eq + 1));
+    pos = end + 1;
+  }
+}
 
 int fail(ian_handle* h, int code, const char* fmt, ...) {
   char buf[1024];
@@ -834,7 +871,7 @@ int run_tapgemm(ian_handle* h, TgLayer& L, int nimg, const float* x, float* y, i
     r.slab = h->d_slab; r.y = y; r.tiles = S->d_tiles; r.classes = L.d_classes; r.epi = epi;
     r.M = p.M; r.qw_shift = p.qw_shift; r.qhw_shift = p.qhw_shift; r.so = L.so; r.OH = L.OH; r.OW = L.OW;
     r.Cout = L.Cout; r.y_stride = y_stride;
-    HIPCHK(h, launch_tapgemm_reduce(S->cfg, r, S->ntiles, S->max_nsplit >= 8 ? 4 : 1, st));
+    HIPCHK(h, launch_tapgemm_reduce(S->cfg, r, S->ntiles, (S->max_nsplit >= 8 && h->opt.tg_reduce_kp > 1) ? 4 : 1, st));
   }
   if (ev) {
     HIPCHK(h, hipEventRecord(ev->second, st));
@@ -1702,6 +1739,7 @@ const char* ian_last_error(ian_handle* h) { return h ? h->err.c_str() : "null ha
 int ian_create(const ian_model_desc* desc, ian_handle** out) {
   if (!desc || !out) return -1;
   std::unique_ptr<ian_handle> h(new ian_handle());
+  apply_env_options(h->opt);
   h->desc = *desc;
   h->strings.reserve((size_t)desc->n_ops * 2 + 4);
   h->ops.resize(desc->n_ops);
@@ -2146,22 +2184,7 @@ int ian_profile_read(ian_handle* h, double* tapgemm_ms, int64_t* tapgemm_launche
 
 int ian_set_option(ian_handle* h, const char* key, int32_t value) {
   if (!h || !key) return -1;
-  const std::string k(key);
-  if (k == "tg_cfg") h->opt.tg_cfg = value;
-  else if (k == "tg_target_items") h->opt.tg_target_items = std::max(1, value);
-  else if (k == "tg_min_steps") h->opt.tg_min_steps = std::max(1, value);
-  else if (k == "tg_no_split_items") h->opt.tg_no_split_items = value;
-  else if (k == "tg_split") h->opt.tg_split = value;
-  else if (k == "tg_xcd_group") h->opt.tg_xcd_group = std::max(1, value);
-  else if (k == "tg_prefer_nosplit") h->opt.tg_prefer_nosplit = value;
-  else if (k == "tg_nosplit_min_out") h->opt.tg_nosplit_min_out = value;
-  else if (k == "tg_variant") h->opt.tg_variant = value;
-  else if (k == "mdc_head") h->opt.mdc_head = value;
-  else if (k == "head_fused") h->opt.head_fused = value;
-  else if (k == "edit_graph") h->opt.edit_graph = value;
-  else if (k == "dec_out_mfma") h->opt.dec_out_mfma = value;
-  else if (k == "head_fused_min_n") h->opt.head_fused_min_n = std::max(1, value);
-  else return fail(h, -1, "unknown option '%s'", key);
+  if (!apply_option(h->opt, key, value)) return fail(h, -1, "unknown option '%s'", key);
   for (auto& op : h->ops) {  // schedules depend on the options
     free_schedules(op.fwd);
     free_schedules(op.bwd);
@@ -2333,6 +2356,7 @@ int ian_layer_create(const ian_op_desc* desc, int32_t deconv_flip, ian_layer** o
   }
   std::unique_ptr<ian_layer> l(new ian_layer());
   ian_handle* h = &l->ctx;
+  apply_env_options(h->opt);
   h->desc.deconv_flip = deconv_flip;
   h->finalized = true;
   OpPlan& op = l->op;
