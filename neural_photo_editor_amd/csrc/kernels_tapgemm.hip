@@ -301,25 +301,30 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
     }
     tg_compute<FM, FN>(a_base + cur * BM * TG_LDS, b_base + cur * BN * TG_LDS, acc);
   } else {
+    // VAR 2 = the production schedule.  VAR 10 / 11 / 12 are TIMING-ONLY ablations of it (results are wrong): without the
+    // global loads + LDS stores, without the barrier, without the fragment reads -- what is left of the 22 % of cycles
+    // in which the matrix pipe idles (scripts/ablate_tapgemm.sh)
+    constexpr bool NOLOAD = (VAR == 10), NOBAR = (VAR == 11), NOFRAG = (VAR == 12);
     float4 av[FM], bv[FN], aw[FM], bw[FN];
     tg_frag_load<FM, FN>(a_base, b_base, 0, av, bv);
+    if (NOFRAG) tg_frag_load<FM, FN>(a_base, b_base, 1, aw, bw);
     for (int s = 0; s < nks - 1; ++s) {
       const float* a_s = a_base + cur * BM * TG_LDS;
       const float* b_s = b_base + cur * BN * TG_LDS;
-      TG_LOAD_TILE();
+      if (!NOLOAD) TG_LOAD_TILE();
       __builtin_amdgcn_sched_barrier(0);
-      tg_frag_load<FM, FN>(a_s, b_s, 1, aw, bw);
+      if (!NOFRAG) tg_frag_load<FM, FN>(a_s, b_s, 1, aw, bw);
       tg_frag_mfma<FM, FN>(av, bv, acc);   // kk 0 (fragments read before the previous barrier / in the prologue)
-      tg_frag_load<FM, FN>(a_s, b_s, 2, av, bv);
+      if (!NOFRAG) tg_frag_load<FM, FN>(a_s, b_s, 2, av, bv);
       tg_frag_mfma<FM, FN>(aw, bw, acc);   // kk 1
       __builtin_amdgcn_sched_barrier(0);
-      TG_STORE_TILE(cur ^ 1);
+      if (!NOLOAD) TG_STORE_TILE(cur ^ 1);
       __builtin_amdgcn_sched_barrier(0);
-      tg_frag_load<FM, FN>(a_s, b_s, 3, aw, bw);
+      if (!NOFRAG) tg_frag_load<FM, FN>(a_s, b_s, 3, aw, bw);
       tg_frag_mfma<FM, FN>(av, bv, acc);   // kk 2
-      __syncthreads();                     // all reads of `cur` (incl. kk 3 into aw/bw) and all writes of cur^1 done
+      if (!NOBAR) __syncthreads();         // all reads of `cur` (incl. kk 3 into aw/bw) and all writes of cur^1 done
       cur ^= 1;
-      tg_frag_load<FM, FN>(a_base + cur * BM * TG_LDS, b_base + cur * BN * TG_LDS, 0, av, bv);
+      if (!NOFRAG) tg_frag_load<FM, FN>(a_base + cur * BM * TG_LDS, b_base + cur * BN * TG_LDS, 0, av, bv);
       __builtin_amdgcn_sched_barrier(0);
       tg_frag_mfma<FM, FN>(aw, bw, acc);   // kk 3 of the previous buffer: covers the new buffer's first reads
     }
@@ -458,8 +463,13 @@ static hipError_t launch_cfg(const TgParams& p, int nitems, hipStream_t s) {
   switch (p.variant) {
     case 1: return launch_var<BM, BN, WM, WN, 1>(p, nitems, s);
     case 2: return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);
-    default: return launch_var<BM, BN, WM, WN, 0>(p, nitems, s);
+    case 10: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 10>(p, nitems, s); break;   // timing-only ablations
+    case 11: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 11>(p, nitems, s); break;
+    case 12: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 12>(p, nitems, s); break;
+    default: break;
   }
+  if (p.variant >= 10) return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);
+  return launch_var<BM, BN, WM, WN, 0>(p, nitems, s);
 }
 
 hipError_t launch_tapgemm(int cfg, const TgParams& p, int nitems, hipStream_t s) {
