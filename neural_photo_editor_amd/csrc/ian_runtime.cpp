@@ -1203,7 +1203,7 @@ std::vector<TgChoice> tune_candidates(const TgLayer& L, int nimg) {
         if (slabs * sh.bm * sh.bn * 4 > (512ll << 20)) continue;  // slab workspace cap
         if (slabs > 16384) continue;
       }
-      for (int var : {1, 2}) {
+      for (int var : {1, 2, 3}) {
         TgChoice c;
         c.cfg = cfg;
         c.max_steps = ms;

@@ -140,6 +140,20 @@ __device__ __forceinline__ void tg_frag_mfma(const float4 (&av)[FM], const float
     }
 }
 
+// VAR 3 (LDS-DMA staging): rows are 32 floats, unpadded, their eight 16-byte slots XOR-swizzled by (row >> 1) & 7.
+// a_s / b_s point at the lane's row; kk selects the 8-wide k group, half the 4-wide half of it.
+template <int FM, int FN>
+__device__ __forceinline__ void tg_frag_load_sw(const float* a_s, const float* b_s, int kk, int half, int keyA, int keyB,
+                                                float4 (&av)[FM], float4 (&bv)[FN]) {
+  const int sa = (((kk << 1) | half) ^ keyA) << 2, sb = (((kk << 1) | half) ^ keyB) << 2;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) av[i] = *reinterpret_cast<const float4*>(a_s + i * 32 * 32 + sa);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) bv[j] = *reinterpret_cast<const float4*>(b_s + j * 32 * 32 + sb);
+}
+
+typedef __attribute__((address_space(3))) void* tg_lds_ptr;
+
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void tg_store(const TgParams& p, const TgItem& it, const TgClass& cl,
                                          f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wm, int wn, int lane) {
@@ -172,6 +186,8 @@ __device__ __forceinline__ void tg_store(const TgParams& p, const TgItem& it, co
 // VAR selects the K-loop schedule (same arithmetic, same summation order -> bitwise identical results):
 //   0: loads -> 64 MFMAs -> LDS stores -> barrier                (compiler-scheduled)
 //   1: loads -> kk 0,1 -> LDS stores -> kk 2,3 -> barrier         (stores hidden under the second half's MFMAs)
+//   3: as 2, but the tiles travel global -> LDS by LDS-DMA into an XOR-swizzled unpadded image (no staging registers,
+//      no ds_write)
 //   2: rotated: the fragments of the last k group are read before the barrier and their MFMAs issued after it,
 //      covering the barrier, the next tile's global-load issue and the first fragment reads of the new buffer
 template <int BM, int BN, int WM, int WN, int VAR>
@@ -189,16 +205,20 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases, scalar branches
   const int wm = wave / WN, wn = wave % WN;
+  constexpr bool DMA = (VAR == 3);
 
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
   const unsigned w_cls = (unsigned)(cl.w_off * 4);
 
   // ---- staging assignment: thread -> (16-byte chunk c4 of the 128-byte K row, rows r0+32j) ----
-  const int c4 = (tid & 7) * 4;
   const int r0 = tid >> 3;
+  // VAR 3: the thread's 16 bytes land in LDS slot (tid & 7) of its row by construction of the DMA (lane-linear image);
+  // the swizzle therefore goes on the SOURCE: fetch logical chunk (tid & 7) ^ key(row), key = (row >> 1) & 7 -- the
+  // rows r0 + 32 j of one thread share a key
+  const int c4 = DMA ? (((tid & 7) ^ ((r0 >> 1) & 7)) * 4) : (tid & 7) * 4;
   int a_iy0[A_CH], a_ix0[A_CH];
   unsigned a_off[A_CH];  // byte offsets (may wrap for halo pixels; those are replaced by the OOB offset)
   const int qhw_mask = (1 << p.qhw_shift) - 1, qw_mask = (1 << p.qw_shift) - 1;
@@ -260,13 +280,79 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
   const float* a_base = As + arow * TG_LDS + koff;
   const float* b_base = Bs + brow * TG_LDS + koff;
 
+  const int nks = it.ks1 - it.ks0;
+  int cur = 0;
+  if (DMA) {
+    // ---- VAR 3: global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write in the K loop.
+    // One instruction of a wave fills 8 consecutive 128-byte rows (lane l -> row l >> 3, slot l & 7); wave w owns rows
+    // 8w + 32j, exactly the rows its threads addressed in the register-staged variants.  Out-of-range offsets (halo,
+    // ragged tiles) make the hardware write zeros.  The DMAs of K-step s+1 are in flight during the MFMAs of step s;
+    // __syncthreads() drains them (vmcnt(0)) before anybody reads the buffer.
+    float* As3 = smem;                 // [2][BM][32]
+    float* Bs3 = smem + 2 * BM * 32;   // [2][BN][32]
+#define TG_DMA_TILE(buf)                                                                                 \
+  {                                                                                                      \
+    const TgTap tp = p.taps[cl.tap0 + tap];                                                              \
+    const unsigned doff = (unsigned)(((tp.dy * p.IW + tp.dx) * p.Cin + (cstep << 5)) * 4);               \
+    _Pragma("unroll") for (int j = 0; j < A_CH; ++j) {                                                   \
+      const int iy = a_iy0[j] + tp.dy, ix = a_ix0[j] + tp.dx;                                            \
+      const bool ok = ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);                 \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (tg_lds_ptr)(As3 + ((buf) * BM + wave * 8 + 32 * j) * 32), 16, \
+                                               ok ? a_off[j] + doff : 0xFFFFFFF0u, 0, 0, 0);             \
+    }                                                                                                    \
+    const unsigned wsoff = w_cls + (unsigned)tap * slab_bytes + (unsigned)(cstep << 7);                  \
+    _Pragma("unroll") for (int j = 0; j < B_CH; ++j)                                                     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (tg_lds_ptr)(Bs3 + ((buf) * BN + wave * 8 + 32 * j) * 32), 16, \
+                                               w_row + j * w_rstep, wsoff, 0, 0);                        \
+    if (++cstep == kpt) {                                                                                \
+      cstep = 0;                                                                                         \
+      ++tap;                                                                                             \
+    }                                                                                                    \
+  }
+    const int half = lane >> 5;
+    const int keyA = (arow >> 1) & 7, keyB = (brow >> 1) & 7;   // + 32 i does not change the key
+    const float* a3 = As3 + arow * 32;
+    const float* b3 = Bs3 + brow * 32;
+    float4 av[FM], bv[FN], aw[FM], bw[FN];
+    TG_DMA_TILE(0);
+    __syncthreads();
+    tg_frag_load_sw<FM, FN>(a3, b3, 0, half, keyA, keyB, av, bv);
+    for (int s = 0; s < nks - 1; ++s) {
+      const float* a_s = a3 + cur * BM * 32;
+      const float* b_s = b3 + cur * BN * 32;
+      TG_DMA_TILE(cur ^ 1);              // the other buffer: its last readers passed the previous barrier
+      __builtin_amdgcn_sched_barrier(0);
+      tg_frag_load_sw<FM, FN>(a_s, b_s, 1, half, keyA, keyB, aw, bw);
+      tg_frag_mfma<FM, FN>(av, bv, acc);
+      tg_frag_load_sw<FM, FN>(a_s, b_s, 2, half, keyA, keyB, av, bv);
+      tg_frag_mfma<FM, FN>(aw, bw, acc);
+      tg_frag_load_sw<FM, FN>(a_s, b_s, 3, half, keyA, keyB, aw, bw);
+      tg_frag_mfma<FM, FN>(av, bv, acc);
+      __syncthreads();                   // DMAs of cur^1 landed (vmcnt(0)), every read of cur issued and returned
+      cur ^= 1;
+      tg_frag_load_sw<FM, FN>(a3 + cur * BM * 32, b3 + cur * BN * 32, 0, half, keyA, keyB, av, bv);
+      __builtin_amdgcn_sched_barrier(0);
+      tg_frag_mfma<FM, FN>(aw, bw, acc);  // kk 3 of the previous buffer covers the first reads of the new one
+    }
+    {
+      const float* a_s = a3 + cur * BM * 32;
+      const float* b_s = b3 + cur * BN * 32;
+      tg_frag_load_sw<FM, FN>(a_s, b_s, 1, half, keyA, keyB, aw, bw);
+      tg_frag_mfma<FM, FN>(av, bv, acc);
+      tg_frag_load_sw<FM, FN>(a_s, b_s, 2, half, keyA, keyB, av, bv);
+      tg_frag_mfma<FM, FN>(aw, bw, acc);
+      tg_frag_load_sw<FM, FN>(a_s, b_s, 3, half, keyA, keyB, aw, bw);
+      tg_frag_mfma<FM, FN>(av, bv, acc);
+      tg_frag_mfma<FM, FN>(aw, bw, acc);
+    }
+#undef TG_DMA_TILE
+  } else {
   TG_LOAD_TILE();
   TG_STORE_TILE(0);
   __syncthreads();
-
-  const int nks = it.ks1 - it.ks0;
-  int cur = 0;
-  if (VAR == 0) {
+  }
+  if (DMA) {
+  } else if (VAR == 0) {
     for (int s = 0; s < nks - 1; ++s) {
       TG_LOAD_TILE();  // K-step s+1: in flight during the MFMAs below
       // hipcc otherwise sinks the loads next to their ds_write (to recycle fragment registers), exposing the
@@ -463,6 +549,7 @@ static hipError_t launch_cfg(const TgParams& p, int nitems, hipStream_t s) {
   switch (p.variant) {
     case 1: return launch_var<BM, BN, WM, WN, 1>(p, nitems, s);
     case 2: return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);
+    case 3: return launch_var<BM, BN, WM, WN, 3>(p, nitems, s);
     case 10: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 10>(p, nitems, s); break;   // timing-only ablations
     case 11: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 11>(p, nitems, s); break;
     case 12: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 12>(p, nitems, s); break;
