@@ -152,7 +152,14 @@ __device__ __forceinline__ void tg_frag_load_sw(const float* a_s, const float* b
   for (int j = 0; j < FN; ++j) bv[j] = *reinterpret_cast<const float4*>(b_s + j * 32 * 32 + sb);
 }
 
-typedef __attribute__((address_space(3))) void* tg_lds_ptr;
+// 16 bytes per lane global -> LDS (buffer_load_dwordx4 ... lds): lds_base is wave-uniform, lane l lands at lds_base + 16 l.
+// The builtin takes an LDS-address-space pointer, which the host half of the split compilation cannot type-check (it
+// silently drops the whole kernel stub): the body exists in the device pass only.
+__device__ __forceinline__ void tg_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_base, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voff, soff, 0, 0);
+#endif
+}
 
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void tg_store(const TgParams& p, const TgItem& it, const TgClass& cl,
@@ -297,13 +304,11 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
     _Pragma("unroll") for (int j = 0; j < A_CH; ++j) {                                                   \
       const int iy = a_iy0[j] + tp.dy, ix = a_ix0[j] + tp.dx;                                            \
       const bool ok = ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);                 \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (tg_lds_ptr)(As3 + ((buf) * BM + wave * 8 + 32 * j) * 32), 16, \
-                                               ok ? a_off[j] + doff : 0xFFFFFFF0u, 0, 0, 0);             \
+      tg_dma16(xrsrc, As3 + ((buf) * BM + wave * 8 + 32 * j) * 32, ok ? a_off[j] + doff : 0xFFFFFFF0u, 0);  \
     }                                                                                                    \
     const unsigned wsoff = w_cls + (unsigned)tap * slab_bytes + (unsigned)(cstep << 7);                  \
     _Pragma("unroll") for (int j = 0; j < B_CH; ++j)                                                     \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (tg_lds_ptr)(Bs3 + ((buf) * BN + wave * 8 + 32 * j) * 32), 16, \
-                                               w_row + j * w_rstep, wsoff, 0, 0);                        \
+      tg_dma16(wrsrc, Bs3 + ((buf) * BN + wave * 8 + 32 * j) * 32, w_row + j * w_rstep, wsoff);          \
     if (++cstep == kpt) {                                                                                \
       cstep = 0;                                                                                         \
       ++tap;                                                                                             \
