@@ -127,6 +127,8 @@ def train_step_bench(batch, rank, world, iters=3):
     Z = torch.from_numpy(rs.randn(batch, 100).astype(np.float32)).cuda()
     eps = torch.from_numpy(rs.randn(batch, 100).astype(np.float32)).cuda()
     out = {}
+    if not os.environ.get("IAN_NO_AUTOTUNE"):
+        tr.autotune()                                            # untimed: per-layer schedules for this batch on this GPU
     for which in ("gen", "discrim"):
         tr.step(which, X, Z, eps, return_metrics=False)          # warm-up (schedules, workspaces)
         torch.cuda.synchronize()

@@ -53,6 +53,12 @@ int ian_layer_backward_data(ian_layer* l, const float* dy, int32_t n, float* dx,
 /* dparams[i] (+)= d loss / d param_i in the reference layout (same order as set_params). */
 int ian_layer_backward_weight(ian_layer* l, const float* x, const float* dy, int32_t n, float* const* dparams,
                               int32_t nparams, int32_t accumulate, void* stream);
+/* Time candidate (tile shape x split-K x K-loop schedule) decompositions of this layer's forward and backward-data
+   launches for batch n on this device and keep the fastest (same contract as ian_autotune: results are identical for
+   every choice up to float32 summation order).  scratch_a / scratch_b: device buffers of cap_floats floats each, filled
+   by the caller with random values (zero-filled operands run at a higher clock and would bias the choice); they are
+   used as input / output of the timed launches and are overwritten. */
+int ian_layer_autotune(ian_layer* l, int32_t n, float* scratch_a, float* scratch_b, int64_t cap_floats, void* stream);
 const char* ian_layer_last_error(ian_layer* l);
 void ian_layer_destroy(ian_layer* l);
 

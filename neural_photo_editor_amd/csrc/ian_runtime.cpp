@@ -2593,6 +2593,30 @@ int ian_layer_backward_weight(ian_layer* l, const float* x, const float* dy, int
   return 0;
 }
 
+int ian_layer_autotune(ian_layer* l, int32_t n, float* scratch_a, float* scratch_b, int64_t cap_floats, void* stream) {
+  if (!l || !scratch_a || !scratch_b || n <= 0) return lfail(l, -1, "bad argument to ian_layer_autotune");
+  hipStream_t st = (hipStream_t)stream;
+  ian_handle* h = &l->ctx;
+  TgEpilogue e;
+  e.scale = nullptr; e.shift = nullptr; e.res = nullptr; e.yfwd = nullptr; e.act = IAN_ACT_NONE; e.scale_period = 0; e.mode = TG_EPI_FWD;
+  struct Dir { TgLayer* L; float* in; float* out; };
+  Dir dirs[2] = {{&l->op.fwd, scratch_a, scratch_b}, {&l->op.bwd, scratch_b, scratch_a}};
+  for (int d = 0; d < 2; ++d) {
+    TgLayer& L = *dirs[d].L;
+    if (!L.valid) continue;
+    if (d == 0 && l->op.d.kind == IAN_OP_MDC3 && (mdc_head_eligible(h, l->op) || mdc_thin_eligible(h, L))) continue;  // VALU kernels
+    if (d == 1 && l->op.d.kind == IAN_OP_MDC3 && mdc_thin_eligible(h, L)) continue;
+    const int ystride = round_up(L.Cout, 32);
+    const int64_t need_in = (int64_t)n * L.IH * L.IW * L.Cin, need_out = (int64_t)n * L.OH * L.OW * ystride;
+    if (need_in > cap_floats || need_out > cap_floats) return lfail(l, -7, "ian_layer_autotune: scratch buffers too small (%lld floats needed)", (long long)std::max(need_in, need_out));
+    float* in = dirs[d].in;
+    float* out = dirs[d].out;
+    int rc = tune_layer(h, L, n, st, [&]() { return run_tapgemm(h, L, n, in, out, ystride, e, st); }, nullptr, nullptr);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 void ian_layer_destroy(ian_layer* l) {
   if (!l) return;
   for (TgLayer* L : {&l->op.fwd, &l->op.bwd}) {

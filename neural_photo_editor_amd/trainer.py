@@ -165,6 +165,10 @@ class Layer:
         self._chk(self.lib.ian_layer_backward_weight(self.h, _p(x), _p(dy), n, self._ptrs(dparams), len(dparams), int(accumulate),
                                                      C.c_void_p(stream)))
 
+    def autotune(self, n, scratch_a, scratch_b, stream=0):
+        self._chk(self.lib.ian_layer_autotune(self.h, n, _p(scratch_a), _p(scratch_b), min(scratch_a.numel(), scratch_b.numel()),
+                                              C.c_void_p(stream)))
+
     def close(self):
         if self.h:
             self.lib.ian_layer_destroy(self.h)
@@ -403,6 +407,18 @@ class Trainer:
                 self.fc2_bias = self.torch.empty(8192, dtype=self.torch.float32, device=self.dev)
             k.gather(self.P("l_dec_fc2.b"), self.fc2_perm, self.fc2_bias, 8192)
         self._dirty = set()
+
+    def autotune(self):
+        """Pick tile shape / split-K / K-loop schedule per layer for this per-rank batch by timing the real launches on this
+        GPU (untimed set-up work, like API.IAN's ian_autotune; summation order aside, results do not change)."""
+        torch = self.torch
+        need = self.n * 64 * 64 * 128                      # the largest activation of IAN.py (dec_conv4 output)
+        a = torch.randn(need, dtype=torch.float32, device=self.dev)
+        b = torch.randn(need, dtype=torch.float32, device=self.dev)
+        self.refresh_weights()
+        for name, (layer, pnames) in self.layers.items():
+            layer.autotune(self.n, a, b)
+        torch.cuda.synchronize()
 
     def mark_params_changed(self, *groups):
         """Call after writing parameter values behind the trainer's back (tests, checkpoint loading)."""

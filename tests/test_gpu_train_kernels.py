@@ -307,3 +307,33 @@ def test_sampling_iaf_losses_ortho_adam(env):
         vr = 0.999 * vr + 0.001 * g.astype(np.float64) ** 2
         pr = pr - a_t * mr / (np.sqrt(vr) + 1e-8)
     assert np.abs(pd_.cpu().numpy() - pr).max() < 1e-6
+
+
+def test_layer_autotune_keeps_the_arithmetic(env):
+    """ian_layer_autotune only changes the (tile, split-K, K-loop schedule) decomposition: forward / backward-data results
+    before and after agree to float32 summation order."""
+    lib, T, k = env
+    n, cin, cout, h = 8, 64, 96, 16
+    rs = np.random.RandomState(4)
+    W = (rs.randn(cin, cout, 5, 5) * 0.05).astype(np.float32)
+    x = rs.randn(n, cin, h, h).astype(np.float32)
+    dy = rs.randn(n, cout, 2 * h, 2 * h).astype(np.float32)
+    layer = T.Layer(lib, T.K_DECONV, cin, cout, h, h)
+    Wd = torch.from_numpy(W.ravel()).cuda()
+    layer.set_params([Wd])
+    xd, dyd = to_nhwc(x), to_nhwc(dy)
+    y0 = torch.zeros(n, 2 * h, 2 * h, cs(cout), device="cuda")
+    dx0 = torch.zeros(n, h, h, cs(cin), device="cuda")
+    layer.forward(xd, n, y0)
+    layer.backward_data(dyd, n, dx0)
+    a = torch.randn(n * 32 * 32 * 128, device="cuda")
+    b = torch.randn(n * 32 * 32 * 128, device="cuda")
+    layer.autotune(n, a, b)
+    y1, dx1 = torch.zeros_like(y0), torch.zeros_like(dx0)
+    layer.forward(xd, n, y1)
+    layer.backward_data(dyd, n, dx1)
+    assert rel(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-5 and rel(dx1.cpu().numpy(), dx0.cpu().numpy()) < 1e-5
+    ref = F.conv_transpose2d(torch.tensor(x, dtype=torch.float64), torch.flip(torch.tensor(W, dtype=torch.float64), (2, 3)), stride=2,
+                             padding=2, output_padding=1).numpy()
+    assert rel(from_nhwc(y1, cout), ref) < TOL
+    layer.close()
