@@ -53,6 +53,12 @@ int ian_layer_backward_data(ian_layer* l, const float* dy, int32_t n, float* dx,
 /* dparams[i] (+)= d loss / d param_i in the reference layout (same order as set_params). */
 int ian_layer_backward_weight(ian_layer* l, const float* x, const float* dy, int32_t n, float* const* dparams,
                               int32_t nparams, int32_t accumulate, void* stream);
+/* Forward of THREE 2-filter MDCL layers that read the same 128-channel map with the same tap list (the R, G_a, B_a layers
+   of the RGB-Beta head, IAN.py:183-199) in one pass over the map: y_k = act_k(x (*) W_k), k = 0..2, each an NHWC map with
+   pixel stride y_stride (kernels_head.hip head6_kernel: one dense 128 -> 6*taps contraction per pixel on the matrix
+   cores + shifted adds).  Returns -4 when the layers do not have that shape (use ian_layer_forward then). */
+int ian_layer_head6_forward(ian_layer* l0, ian_layer* l1, ian_layer* l2, const float* x, int32_t n, float* y0, float* y1,
+                            float* y2, int32_t y_stride, int32_t act0, int32_t act1, int32_t act2, void* stream);
 /* Time candidate (tile shape x split-K x K-loop schedule) decompositions of this layer's forward and backward-data
    launches for batch n on this device and keep the fastest (same contract as ian_autotune: results are identical for
    every choice up to float32 summation order).  scratch_a / scratch_b: device buffers of cap_floats floats each, filled

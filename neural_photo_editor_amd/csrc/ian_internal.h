@@ -183,6 +183,7 @@ struct HeadFusedArgs {
   long long w_tap_stride;
 };
 hipError_t launch_head6(const HeadFusedArgs& a, int n, hipStream_t s);
+hipError_t launch_head6_scatter(const float* comp, float* y0, float* y1, float* y2, int ys, long long npix, hipStream_t s);
 struct HeadTailArgs {
   const float* comp;       // compact map: (R0,R1,Ga0,Ga1,Ba0,Ba1,-,-) per pixel
   const float *w_gb, *w_bb;  // forward slabs of G_b (2 in) and B_b (4 in): [tap][CoutPad][CinPad]

@@ -2593,6 +2593,65 @@ int ian_layer_backward_weight(ian_layer* l, const float* x, const float* dy, int
   return 0;
 }
 
+int ian_layer_head6_forward(ian_layer* l0, ian_layer* l1, ian_layer* l2, const float* x, int32_t n, float* y0, float* y1,
+                            float* y2, int32_t y_stride, int32_t act0, int32_t act1, int32_t act2, void* stream) {
+  if (!l0 || !l1 || !l2 || !x || !y0 || !y1 || !y2 || n <= 0) return lfail(l0, -1, "bad argument to ian_layer_head6_forward");
+  hipStream_t st = (hipStream_t)stream;
+  ian_layer* ls[3] = {l0, l1, l2};
+  const TgLayer& L = l0->op.fwd;
+  for (ian_layer* l : ls) {
+    const TgLayer& M = l->op.fwd;
+    if (!l->is_mdc || l->op.d.cin != 128 || l->op.d.cout != 2 || l->op.d.in_w != 64 || M.Cin != 128 || !same_taps(L, M)) return -4;
+  }
+  if (L.taps.size() > 37) return -4;
+  ian_handle* h = &l0->ctx;
+  HeadPlan& P = h->head;   // tables + compact workspace live in the first layer's context
+  if (!P.d_itab) {
+    std::vector<int> itab(44, -1), used(9, 0);
+    int halo = 0;
+    for (size_t t = 0; t < L.taps.size(); ++t) {
+      const int dy = L.taps[t].dy, dx = L.taps[t].dx;
+      if (dy < -4 || dy > 4 || dx < -63 || dx > 63) return -4;
+      const int g = dy == 0 ? 0 : (dy < 0 ? dy + 5 : dy + 4), cap = g == 0 ? 12 : 4, s0 = g == 0 ? 0 : 12 + (g - 1) * 4;
+      if (used[g] >= cap) return -4;
+      itab[s0 + used[g]++] = (int)t | ((dx + 64) << 8);
+      halo = std::max(halo, std::abs(dy));
+    }
+    P.halo = halo;
+    int rc = upload(h, itab, &P.d_itab);
+    if (rc) return rc;
+    LHIP(l0, hipMalloc((void**)&P.d_ftab, 32 * sizeof(float)));
+  }
+  const int acts[3] = {act0, act1, act2};
+  const int act_key = 1 + act0 + 16 * act1 + 256 * act2;
+  if (P.opBeta != act_key) {   // (field reused as "epilogue table uploaded for these activations"): synchronous, first call only
+    float ftab[32] = {0};
+    for (int k = 0; k < 3; ++k)
+      for (int c = 0; c < 2; ++c) { ftab[2 * k + c] = 1.f; ftab[16 + 2 * k + c] = (float)acts[k]; }
+    LHIP(l0, hipStreamSynchronize(st));
+    LHIP(l0, hipMemcpy(P.d_ftab, ftab, sizeof ftab, hipMemcpyHostToDevice));
+    P.opBeta = act_key;
+  }
+  const int H = l0->op.d.in_h, W = l0->op.d.in_w;
+  const size_t need = (size_t)n * H * W * 8;
+  if (need > P.comp_cap) {
+    if (P.d_comp) LHIP(l0, hipFree(P.d_comp));
+    LHIP(l0, hipMalloc((void**)&P.d_comp, need * sizeof(float)));
+    P.comp_cap = need;
+  }
+  HeadFusedArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.w0 = l0->op.fwd.d_w; a.w1 = l1->op.fwd.d_w; a.w2 = l2->op.fwd.d_w; a.out = P.d_comp; a.itab = P.d_itab; a.ftab = P.d_ftab;
+  a.H = H; a.W = W; a.xs = L.Cin; a.ntaps = (int)L.taps.size(); a.halo = P.halo;
+  a.w_tap_stride = (long long)L.CoutPad * L.Cin;
+  int bands = 1;
+  while (n * bands < 256 && bands < 8 && (H % (bands * 2)) == 0 && H / (bands * 2) >= 2 * P.halo) bands *= 2;
+  a.bands = bands;
+  LHIP(l0, launch_head6(a, n, st));
+  LHIP(l0, launch_head6_scatter(P.d_comp, y0, y1, y2, y_stride, (long long)n * H * W, st));
+  return 0;
+}
+
 int ian_layer_autotune(ian_layer* l, int32_t n, float* scratch_a, float* scratch_b, int64_t cap_floats, void* stream) {
   if (!l || !scratch_a || !scratch_b || n <= 0) return lfail(l, -1, "bad argument to ian_layer_autotune");
   hipStream_t st = (hipStream_t)stream;
@@ -2628,7 +2687,7 @@ void ian_layer_destroy(ian_layer* l) {
   for (auto& kv : l->wsched)
     if (kv.second.d_items) (void)hipFree(kv.second.d_items);
   for (void* p : {(void*)l->d_fwd_map, (void*)l->d_bwd_map, (void*)l->d_inv_map, (void*)l->d_partial, (void*)l->d_dS,
-                  (void*)l->ctx.d_slab})
+                  (void*)l->ctx.d_slab, (void*)l->ctx.head.d_itab, (void*)l->ctx.head.d_ftab, (void*)l->ctx.head.d_comp})
     if (p) (void)hipFree(p);
   delete l;
 }

@@ -293,6 +293,23 @@ __global__ __launch_bounds__(HT_T) void head_tail_kernel(HeadTailArgs a) {
   }
 }
 
+// compact map of head6_kernel -> three NHWC 2-channel maps (training: the backward pass and G_b / B_b want them apart)
+__global__ __launch_bounds__(256) void head6_scatter_kernel(const float* __restrict__ comp, float* __restrict__ y0,
+                                                            float* __restrict__ y1, float* __restrict__ y2, int ys, long long npix) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npix) return;
+  const float4 a = *reinterpret_cast<const float4*>(comp + p * 8);
+  const float2 b = *reinterpret_cast<const float2*>(comp + p * 8 + 4);
+  *reinterpret_cast<float2*>(y0 + p * ys) = make_float2(a.x, a.y);
+  *reinterpret_cast<float2*>(y1 + p * ys) = make_float2(a.z, a.w);
+  *reinterpret_cast<float2*>(y2 + p * ys) = b;
+}
+hipError_t launch_head6_scatter(const float* comp, float* y0, float* y1, float* y2, int ys, long long npix, hipStream_t s) {
+  if (ys & 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(head6_scatter_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, comp, y0, y1, y2, ys, npix);
+  return hipGetLastError();
+}
+
 hipError_t launch_head_tail(const HeadTailArgs& a, int n, hipStream_t s) {
   if (a.ntaps > 48 || a.H * a.W > 4096) return hipErrorInvalidValue;
   const size_t lds = (size_t)(a.H * a.W * 6 + a.ntaps * 12) * sizeof(float);

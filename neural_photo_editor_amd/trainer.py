@@ -165,6 +165,15 @@ class Layer:
         self._chk(self.lib.ian_layer_backward_weight(self.h, _p(x), _p(dy), n, self._ptrs(dparams), len(dparams), int(accumulate),
                                                      C.c_void_p(stream)))
 
+    def head6_forward(self, l1, l2, x, n, y0, y1, y2, y_stride, acts, stream=0):
+        """Three sibling 2-filter MDCL layers in one pass (ian_layer_head6_forward); False when the shape does not qualify."""
+        rc = self.lib.ian_layer_head6_forward(self.h, l1.h, l2.h, _p(x), n, _p(y0), _p(y1), _p(y2), y_stride, acts[0], acts[1], acts[2],
+                                              C.c_void_p(stream))
+        if rc == -4:
+            return False
+        self._chk(rc)
+        return True
+
     def autotune(self, n, scratch_a, scratch_b, stream=0):
         self._chk(self.lib.ian_layer_autotune(self.h, n, _p(scratch_a), _p(scratch_b), min(scratch_a.numel(), scratch_b.numel()),
                                               C.c_void_p(stream)))
@@ -283,6 +292,7 @@ class Trainer:
         self._dirty = {"enc", "Z", "dec"}
         self._plans, self._works, self._fired, self._buckets = {}, [], set(), None
         self._ev, self._evlog, self.overlap_log = 0, [], []
+        self.head6 = True                        # RGB-Beta head: R / G_a / B_a forward in one pass (kernels_head.hip)
         self.overlap = True                      # data parallel: all-reduce gradient buckets while backward still runs
         self.side = torch.cuda.Stream() if self.comm.world > 1 else None
         self.touched = _WriteLog(self)
@@ -653,10 +663,12 @@ class Trainer:
         lay("dec_conv4").forward(h, n, D["y4"])
         self._bn_forward(D["bn4"], D["y4"], D["h4"], rows, 128, 128, self.P("bnorm_dc4.gamma"), self.P("bnorm_dc4.beta"), ACT["lrelu"], rows, rn("bnorm_dc4"))
         sg = ACT["sigmoid"]
-        lay("R").forward(D["h4"], n, D["R"], act=sg)                                          # IAN.py:183-186
-        lay("G_a").forward(D["h4"], n, D["Ga"])
+        # R = sigmoid(MDCL(h4)), G_a, B_a (IAN.py:183-199): the three layers that read the 128-channel map, one pass over it
+        if not (self.head6 and lay("R").head6_forward(lay("G_a"), lay("B_a"), D["h4"], n, D["R"], D["Ga"], D["Ba"], 32, (sg, 0, 0))):
+            lay("R").forward(D["h4"], n, D["R"], act=sg)                                      # IAN.py:183-186
+            lay("G_a").forward(D["h4"], n, D["Ga"])
+            lay("B_a").forward(D["h4"], n, D["Ba"])
         lay("G_b").forward(D["R"], n, D["G"], res=D["Ga"], act=sg)                            # :187-196
-        lay("B_a").forward(D["h4"], n, D["Ba"])
         k.concat2(D["R"], 2, 32, D["G"], 2, 32, D["RG"], 32, rows)                            # :201
         lay("B_b").forward(D["RG"], n, D["B"], res=D["Ba"], act=sg)                           # :197-206
         k.beta(D["R"], D["G"], D["B"], D["xhat"], n, 4096, 32)                                # :207

@@ -337,3 +337,40 @@ def test_layer_autotune_keeps_the_arithmetic(env):
                              padding=2, output_padding=1).numpy()
     assert rel(from_nhwc(y1, cout), ref) < TOL
     layer.close()
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_head6_forward_equals_three_layer_forwards(env, n):
+    """ian_layer_head6_forward (R, G_a, B_a of IAN.py:183-199 in one pass over the 128-channel map) vs the three separate
+    ian_layer_forward calls and vs float64 torch."""
+    lib, T, k = env
+    rs = np.random.RandomState(11 + n)
+    sc = [2, 3, 4]
+    x = rs.randn(n, 128, 64, 64).astype(np.float32)
+    xd = to_nhwc(x)
+    layers, keep, refs = [], [], []
+    for i in range(3):
+        W = (rs.randn(2, 128, 3, 3) * 0.05).astype(np.float32)
+        coeffs = [rs.uniform(0.5, 1.5, 2).astype(np.float32) for _ in range(4)]
+        xt = torch.tensor(x, dtype=torch.float64)
+        Wt = torch.tensor(W, dtype=torch.float64)
+        y = F.conv2d(xt, Wt, padding=1) * torch.tensor(coeffs[0], dtype=torch.float64).reshape(1, -1, 1, 1)
+        for j, s in enumerate(sc):
+            y = y + F.conv2d(xt, Wt, padding=s, dilation=s) * torch.tensor(coeffs[1 + j], dtype=torch.float64).reshape(1, -1, 1, 1)
+        refs.append(torch.sigmoid(y).numpy() if i == 0 else y.numpy())
+        layer = T.Layer(lib, T.K_MDC, 128, 2, 64, 64, scales=sc)
+        params = [torch.from_numpy(a.ravel()).cuda() for a in [W] + coeffs]
+        keep.append(params)
+        layer.set_params(params)
+        layers.append(layer)
+    ys = [torch.zeros(n, 64, 64, 32, device="cuda") for _ in range(3)]
+    assert layers[0].head6_forward(layers[1], layers[2], xd, n, ys[0], ys[1], ys[2], 32, (5, 0, 0))
+    sep = [torch.zeros(n, 64, 64, 32, device="cuda") for _ in range(3)]
+    for i in range(3):
+        layers[i].forward(xd, n, sep[i], act=5 if i == 0 else 0)
+    for i in range(3):
+        assert rel(from_nhwc(ys[i], 2), refs[i]) < TOL, i
+        assert rel(from_nhwc(ys[i], 2), from_nhwc(sep[i], 2)) < 1e-5, i
+        assert float(ys[i][..., 2:].abs().max()) == 0.0          # channel padding untouched
+    for l in layers:
+        l.close()
