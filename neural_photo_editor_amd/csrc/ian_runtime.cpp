@@ -2256,6 +2256,12 @@ struct ian_layer {
   float* d_partial = nullptr;
   size_t partial_cap = 0;
   float* d_dS = nullptr;  // MDC: reduced slab gradient
+  // contract-first backward-weight of three sibling head layers (ian_layer_head6_backward_weight): owned by the first one
+  ian_layer* h6_helper = nullptr;   // dense 128 -> 6*taps layer whose backward-weight is the one GEMM
+  float* h6_Z = nullptr;
+  size_t h6_Z_cap = 0;
+  float* h6_dW = nullptr;
+  int* h6_taps = nullptr;
   std::map<int, WgSchedule> wsched;
 };
 
@@ -2652,6 +2658,62 @@ int ian_layer_head6_forward(ian_layer* l0, ian_layer* l1, ian_layer* l2, const f
   return 0;
 }
 
+int ian_layer_head6_backward_weight(ian_layer* l0, ian_layer* l1, ian_layer* l2, const float* x, const float* dy0,
+                                    const float* dy1, const float* dy2, int32_t n, int32_t dy_stride, float* const* dparams0,
+                                    float* const* dparams1, float* const* dparams2, int32_t nparams, int32_t accumulate,
+                                    void* stream) {
+  if (!l0 || !l1 || !l2 || !x || !dy0 || !dy1 || !dy2 || !dparams0 || !dparams1 || !dparams2 || n <= 0)
+    return lfail(l0, -1, "bad argument to ian_layer_head6_backward_weight");
+  hipStream_t st = (hipStream_t)stream;
+  ian_layer* ls[3] = {l0, l1, l2};
+  float* const* dps[3] = {dparams0, dparams1, dparams2};
+  const TgLayer& L = l0->op.fwd;
+  for (ian_layer* l : ls) {
+    const TgLayer& M = l->op.fwd;
+    if (!l->is_mdc || l->op.d.cin != 128 || l->op.d.cout != 2 || M.Cin != 128 || !same_taps(L, M) || nparams != (int)l->pnumel.size()) return -4;
+  }
+  const int ntaps = (int)L.taps.size(), nout = 6 * ntaps, zs = round_up(nout, 32);
+  const int H = l0->op.d.in_h, W = l0->op.d.in_w;
+  const long long npix = (long long)n * H * W;
+  if (npix * zs * 4 > 0xFFFFFFF0ll || npix > 0x7FFFFFFFll) return -4;   // buffer-descriptor range of the helper GEMM
+  if (!l0->h6_helper) {
+    ian_op_desc d;
+    memset(&d, 0, sizeof d);
+    d.kind = IAN_OP_DENSE; d.cin = 128; d.cout = nout; d.in_h = d.in_w = 1; d.src2 = d.src3 = -1;
+    int rc = ian_layer_create(&d, 1, &l0->h6_helper);
+    if (rc) return lfail(l0, rc, "head6 backward-weight: helper layer creation failed (%d)", rc);
+    std::vector<int> tp(ntaps);
+    for (int t = 0; t < ntaps; ++t) tp[t] = (L.taps[t].dy + 64) | ((L.taps[t].dx + 64) << 8);
+    if ((rc = upload(&l0->ctx, tp, &l0->h6_taps))) return rc;
+    LHIP(l0, hipMalloc((void**)&l0->h6_dW, (size_t)128 * nout * sizeof(float)));
+  }
+  const size_t need = (size_t)npix * zs;
+  if (need > l0->h6_Z_cap) {
+    if (l0->h6_Z) LHIP(l0, hipFree(l0->h6_Z));
+    LHIP(l0, hipMalloc((void**)&l0->h6_Z, need * sizeof(float)));
+    l0->h6_Z_cap = need;
+  }
+  LHIP(l0, launch_head6_zbuild(dy0, dy1, dy2, dy_stride, l0->h6_Z, zs, H, W, ntaps, l0->h6_taps, npix, st));
+  float* dw_ptr[1] = {l0->h6_dW};
+  int rc = ian_layer_backward_weight(l0->h6_helper, x, l0->h6_Z, (int32_t)npix, dw_ptr, 1, 0, stream);
+  if (rc) return lfail(l0, rc, "head6 backward-weight GEMM: %s", ian_layer_last_error(l0->h6_helper));
+  for (int k = 0; k < 3; ++k) {
+    ian_layer* l = ls[k];
+    LHIP(l, hipMemsetAsync(l->d_dS, 0, l->op.fwd.w_floats * sizeof(float), st));
+    LHIP(l, launch_head6_dS_scatter(l0->h6_dW, nout, k, ntaps, l->d_dS, l->op.fwd.CoutPad, l->op.fwd.Cin, st));
+    MdcCoeffGrads g;
+    memset(&g, 0, sizeof g);
+    g.d[0] = dps[k][1];
+    for (int i = 2; i < nparams; ++i) {
+      const int b = l->mdc_param_branch[i - 1];
+      if (b < 0) g.d1x1 = dps[k][i];
+      else g.d[b] = dps[k][i];
+    }
+    LHIP(l, launch_mdc_unpack_grad(l->mdc, l->d_dS, dps[k][0], g, accumulate, st));
+  }
+  return 0;
+}
+
 int ian_layer_autotune(ian_layer* l, int32_t n, float* scratch_a, float* scratch_b, int64_t cap_floats, void* stream) {
   if (!l || !scratch_a || !scratch_b || n <= 0) return lfail(l, -1, "bad argument to ian_layer_autotune");
   hipStream_t st = (hipStream_t)stream;
@@ -2678,6 +2740,9 @@ int ian_layer_autotune(ian_layer* l, int32_t n, float* scratch_a, float* scratch
 
 void ian_layer_destroy(ian_layer* l) {
   if (!l) return;
+  if (l->h6_helper) ian_layer_destroy(l->h6_helper);
+  for (void* p : {(void*)l->h6_Z, (void*)l->h6_dW, (void*)l->h6_taps})
+    if (p) (void)hipFree(p);
   for (TgLayer* L : {&l->op.fwd, &l->op.bwd}) {
     free_schedules(*L);
     if (L->d_w) (void)hipFree(L->d_w);

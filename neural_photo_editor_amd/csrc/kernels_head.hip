@@ -19,6 +19,8 @@
 //   (R after its sigmoid, G_a and B_a raw), 32 B per pixel instead of 3 x 128 B.
 // head_tail_kernel: one workgroup per image keeps the compact map in LDS (96 KB) and runs G_b (2->2), B_b (4->2), the
 //   sigmoids and the three beta_layers, writing the NCHW image.  ~1.6 M MAC per image: LDS-resident VALU work.
+#include <algorithm>
+
 #include "ian_internal.h"
 
 namespace ian {
@@ -307,6 +309,61 @@ __global__ __launch_bounds__(256) void head6_scatter_kernel(const float* __restr
 hipError_t launch_head6_scatter(const float* comp, float* y0, float* y1, float* y2, int ys, long long npix, hipStream_t s) {
   if (ys & 1) return hipErrorInvalidValue;
   hipLaunchKernelGGL(head6_scatter_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, comp, y0, y1, y2, ys, npix);
+  return hipGetLastError();
+}
+
+// ---- backward-weight of the same three layers, contract-first as well -------------------------------------------------
+//   dS_k[t][f][c] = sum_p dY_k[p][f] * X[p + d_t][c] = sum_q X[q][c] * Z[q][(t,k,f)],   Z[q][(t,k,f)] = dY_k[q - d_t][f]
+// i.e. ONE dense backward-weight GEMM (198 x 128, contraction over all n*H*W pixels: the existing tapwgrad kernel on a
+// helper dense layer) after a cheap shifted gather builds Z -- instead of three VALU passes of 1.04 ms each over X.
+__global__ __launch_bounds__(256) void head6_zbuild_kernel(const float* __restrict__ dy0, const float* __restrict__ dy1,
+                                                           const float* __restrict__ dy2, int dys, float* __restrict__ Z, int zs,
+                                                           int H, int W, int ntaps, const int* __restrict__ taps, long long npix) {
+  // one thread per (pixel, 4 columns): columns j = t*6 + 2k + f
+  const int c4n = zs >> 2;
+  const long long total = npix * c4n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long q = i / c4n;
+    const int j0 = (int)(i % c4n) * 4;
+    const int qx = (int)(q % W), qy = (int)((q / W) % H);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + e;
+      float r = 0.f;
+      if (j < ntaps * 6) {
+        const int t = j / 6, c6 = j % 6, kk = c6 >> 1, f = c6 & 1;
+        const int tp = taps[t];                       // (dy + 64) | (dx + 64) << 8
+        const int py = qy - ((tp & 0xFF) - 64), px = qx - ((tp >> 8) - 64);
+        if ((unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
+          const float* src = kk == 0 ? dy0 : (kk == 1 ? dy1 : dy2);
+          r = src[(q + (long long)(py - qy) * W + (px - qx)) * dys + f];
+        }
+      }
+      v[e] = r;
+    }
+    *reinterpret_cast<float4*>(Z + q * zs + j0) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+hipError_t launch_head6_zbuild(const float* dy0, const float* dy1, const float* dy2, int dys, float* Z, int zs, int H, int W,
+                               int ntaps, const int* taps, long long npix, hipStream_t s) {
+  if (zs & 3) return hipErrorInvalidValue;
+  long long total = npix * (zs >> 2);
+  int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 64);
+  hipLaunchKernelGGL(head6_zbuild_kernel, dim3(blocks), dim3(256), 0, s, dy0, dy1, dy2, dys, Z, zs, H, W, ntaps, taps, npix);
+  return hipGetLastError();
+}
+// dWref[c][j] (the helper dense layer's reference layout W(in = 128, out = 6*ntaps)) -> layer k's slab gradient
+// dS[(t * f_rows + f) * f_cols + c], j = t*6 + 2k + f
+__global__ __launch_bounds__(256) void head6_dS_scatter_kernel(const float* __restrict__ dWref, int nout, int kk, int ntaps,
+                                                               float* __restrict__ dS, int f_rows, int f_cols) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ntaps * 2 * 128) return;
+  const int c = i % 128, f = (i / 128) & 1, t = i / 256;
+  dS[((size_t)t * f_rows + f) * f_cols + c] = dWref[(size_t)c * nout + t * 6 + 2 * kk + f];
+}
+hipError_t launch_head6_dS_scatter(const float* dWref, int nout, int kk, int ntaps, float* dS, int f_rows, int f_cols, hipStream_t s) {
+  hipLaunchKernelGGL(head6_dS_scatter_kernel, dim3((ntaps * 256 + 255) / 256), dim3(256), 0, s, dWref, nout, kk, ntaps, dS, f_rows, f_cols);
   return hipGetLastError();
 }
 

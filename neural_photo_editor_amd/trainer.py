@@ -174,6 +174,17 @@ class Layer:
         self._chk(rc)
         return True
 
+    def head6_backward_weight(self, l1, l2, x, dys, n, dy_stride, dparams3, accumulate=False, stream=0):
+        """Backward-weight of the same three layers as ONE dense contraction (ian_layer_head6_backward_weight); False when the
+        shape does not qualify."""
+        rc = self.lib.ian_layer_head6_backward_weight(self.h, l1.h, l2.h, _p(x), _p(dys[0]), _p(dys[1]), _p(dys[2]), n, dy_stride,
+                                                      self._ptrs(dparams3[0]), self._ptrs(dparams3[1]), self._ptrs(dparams3[2]),
+                                                      len(dparams3[0]), int(accumulate), C.c_void_p(stream))
+        if rc == -4:
+            return False
+        self._chk(rc)
+        return True
+
     def autotune(self, n, scratch_a, scratch_b, stream=0):
         self._chk(self.lib.ian_layer_autotune(self.h, n, _p(scratch_a), _p(scratch_b), min(scratch_a.numel(), scratch_b.numel()),
                                               C.c_void_p(stream)))
@@ -490,6 +501,19 @@ class Trainer:
         layer.backward_weight(x, dy, n, [self.G(p) for p in pnames], accumulate=acc)
         self.touched.update(pnames)
 
+    def _wgrad_head(self, x, dR, dG, dB, n):
+        """R / G_a / B_a weight gradients (IAN.py:183-199): one contract-first pass, or the three separate calls."""
+        names = ("R", "G_a", "B_a")
+        ls = [self.layers[nm] for nm in names]
+        accs = [pn[0] in self.touched for _, pn in ls]
+        if self.head6 and len(set(accs)) == 1 and ls[0][0].head6_backward_weight(
+                ls[1][0], ls[2][0], x, (dR, dG, dB), n, 32, [[self.G(p) for p in pn] for _, pn in ls], accumulate=accs[0]):
+            for _, pn in ls:
+                self.touched.update(pn)
+            return
+        for nm, dy in zip(names, (dR, dG, dB)):
+            self._wgrad(nm, x, dy, n)
+
     # ---------------------------------------------------------------------------------------------
     # encoder pass (IAN.py:71-110 + discriminator head :209-216), training mode
     # ---------------------------------------------------------------------------------------------
@@ -683,7 +707,6 @@ class Trainer:
         # B = sigmoid(B_a(h4) + B_b([R,G]))
         if want_w:
             self._wgrad("B_b", D["RG"], D["gB"], n)
-            self._wgrad("B_a", D["h4"], D["gB"], n)
         lay("B_b").backward_data(D["gB"], n, D["dRG"])
         lay("B_a").backward_data(D["gB"], n, D["dh4"])
         k.grad_pass(D["dRG"], 32, 0, D["gR"], D["R"], 32, rows, 2, sg, 1)
@@ -691,13 +714,12 @@ class Trainer:
         # G = sigmoid(G_a(h4) + G_b(R))
         if want_w:
             self._wgrad("G_b", D["R"], D["gG"], n)
-            self._wgrad("G_a", D["h4"], D["gG"], n)
         lay("G_b").backward_data(D["gG"], n, D["dRt"])
         k.grad_pass(D["dRt"], 32, 0, D["gR"], D["R"], 32, rows, 2, sg, 1)
         lay("G_a").backward_data(D["gG"], n, D["dh4"], accumulate=True)
         # R = sigmoid(R(h4))
         if want_w:
-            self._wgrad("R", D["h4"], D["gR"], n)
+            self._wgrad_head(D["h4"], D["gR"], D["gG"], D["gB"], n)      # all three seeds are final here
         lay("R").backward_data(D["gR"], n, D["dh4"], accumulate=True)
         # dec_conv4 + bnorm_dc4 + lrelu
         self._bn_backward(D["bn4"], D["dh4"], D["h4"], D["y4"], D["dh4"], rows, 128, 128, ACT["lrelu"], "bnorm_dc4.gamma", "bnorm_dc4.beta", want_w)
