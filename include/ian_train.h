@@ -59,15 +59,20 @@ int ian_layer_backward_weight(ian_layer* l, const float* x, const float* dy, int
    cores + shifted adds).  Returns -4 when the layers do not have that shape (use ian_layer_forward then). */
 int ian_layer_head6_forward(ian_layer* l0, ian_layer* l1, ian_layer* l2, const float* x, int32_t n, float* y0, float* y1,
                             float* y2, int32_t y_stride, int32_t act0, int32_t act1, int32_t act2, void* stream);
-/* Backward-weight of the same three layers in one contraction: dparams_k[i] (+)= d loss / d param_i of layer k (order as in
-   ian_layer_set_params), dy_k = gradient wrt the pre-activation output of layer k (NHWC, pixel stride dy_stride).
-   A shifted gather builds Z[q][(t,k,f)] = dy_k[q - d_t][f]; one dense backward-weight GEMM (6*taps x 128, contraction over all
-   n*H*W pixels) gives every slab gradient; the (W, coefficient) gradients follow as in ian_layer_backward_weight.
-   Needs n*H*W*round_up(6*taps,32) floats of scratch, owned by the first layer.  Returns -4 when the shape does not qualify. */
-int ian_layer_head6_backward_weight(ian_layer* l0, ian_layer* l1, ian_layer* l2, const float* x, const float* dy0,
-                                    const float* dy1, const float* dy2, int32_t n, int32_t dy_stride, float* const* dparams0,
-                                    float* const* dparams1, float* const* dparams2, int32_t nparams, int32_t accumulate,
-                                    void* stream);
+/* Backward of the same three layers, contract-first as well.  dy_k = gradient wrt the pre-activation output of layer k (NHWC,
+   pixel stride dy_stride).  A shifted gather builds Z[q][(t,k,f)] = dy_k[q - d_t][f] once; then
+     dx (optional, NHWC stride dx_stride; += when dx_accumulate)  = Z . Wcat      -- ONE dense GEMM, K = 6*taps, instead of
+                                                                                     three tap GEMMs whose K is 94 % padding
+     dparams_k[i] (optional, all three or none; order as in ian_layer_set_params; += when accumulate)
+                                                                  from  X^T . Z   -- ONE dense backward-weight GEMM, then the
+                                                                                     (W, coefficient) gradients as in
+                                                                                     ian_layer_backward_weight.
+   Needs n*H*W*round_up(6*taps,32) floats of scratch, owned by the first layer.  x may be NULL when no dparams are given.
+   Returns -4 when the shape does not qualify (the caller falls back to the per-layer calls). */
+int ian_layer_head6_backward(ian_layer* l0, ian_layer* l1, ian_layer* l2, const float* x, const float* dy0, const float* dy1,
+                             const float* dy2, int32_t n, int32_t dy_stride, float* dx, int32_t dx_stride, int32_t dx_accumulate,
+                             float* const* dparams0, float* const* dparams1, float* const* dparams2, int32_t nparams,
+                             int32_t accumulate, void* stream);
 /* Time candidate (tile shape x split-K x K-loop schedule) decompositions of this layer's forward and backward-data
    launches for batch n on this device and keep the fastest (same contract as ian_autotune: results are identical for
    every choice up to float32 summation order).  scratch_a / scratch_b: device buffers of cap_floats floats each, filled

@@ -185,6 +185,7 @@ struct HeadFusedArgs {
 hipError_t launch_head6(const HeadFusedArgs& a, int n, hipStream_t s);
 hipError_t launch_head6_zbuild(const float* dy0, const float* dy1, const float* dy2, int dys, float* Z, int zs, int H, int W,
                                int ntaps, const int* taps, long long npix, hipStream_t s);
+hipError_t launch_head6_wcat(const float* slab, int f_rows, int f_cols, int kk, int ntaps, float* wcat, int nout, hipStream_t s);
 hipError_t launch_head6_dS_scatter(const float* dWref, int nout, int kk, int ntaps, float* dS, int f_rows, int f_cols, hipStream_t s);
 hipError_t launch_head6_scatter(const float* comp, float* y0, float* y1, float* y2, int ys, long long npix, hipStream_t s);
 struct HeadTailArgs {

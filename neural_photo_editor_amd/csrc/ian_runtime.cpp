@@ -2658,34 +2658,37 @@ int ian_layer_head6_forward(ian_layer* l0, ian_layer* l1, ian_layer* l2, const f
   return 0;
 }
 
-int ian_layer_head6_backward_weight(ian_layer* l0, ian_layer* l1, ian_layer* l2, const float* x, const float* dy0,
-                                    const float* dy1, const float* dy2, int32_t n, int32_t dy_stride, float* const* dparams0,
-                                    float* const* dparams1, float* const* dparams2, int32_t nparams, int32_t accumulate,
-                                    void* stream) {
-  if (!l0 || !l1 || !l2 || !x || !dy0 || !dy1 || !dy2 || !dparams0 || !dparams1 || !dparams2 || n <= 0)
-    return lfail(l0, -1, "bad argument to ian_layer_head6_backward_weight");
+int ian_layer_head6_backward(ian_layer* l0, ian_layer* l1, ian_layer* l2, const float* x, const float* dy0, const float* dy1,
+                             const float* dy2, int32_t n, int32_t dy_stride, float* dx, int32_t dx_stride, int32_t dx_accumulate,
+                             float* const* dparams0, float* const* dparams1, float* const* dparams2, int32_t nparams,
+                             int32_t accumulate, void* stream) {
+  const bool want_w = dparams0 || dparams1 || dparams2;
+  if (!l0 || !l1 || !l2 || !dy0 || !dy1 || !dy2 || n <= 0 || (!dx && !want_w) || (want_w && (!x || !dparams0 || !dparams1 || !dparams2)))
+    return lfail(l0, -1, "bad argument to ian_layer_head6_backward");
   hipStream_t st = (hipStream_t)stream;
   ian_layer* ls[3] = {l0, l1, l2};
   float* const* dps[3] = {dparams0, dparams1, dparams2};
   const TgLayer& L = l0->op.fwd;
   for (ian_layer* l : ls) {
     const TgLayer& M = l->op.fwd;
-    if (!l->is_mdc || l->op.d.cin != 128 || l->op.d.cout != 2 || M.Cin != 128 || !same_taps(L, M) || nparams != (int)l->pnumel.size()) return -4;
+    if (!l->is_mdc || l->op.d.cin != 128 || l->op.d.cout != 2 || M.Cin != 128 || !same_taps(L, M) ||
+        (want_w && nparams != (int)l->pnumel.size()))
+      return -4;
   }
   const int ntaps = (int)L.taps.size(), nout = 6 * ntaps, zs = round_up(nout, 32);
   const int H = l0->op.d.in_h, W = l0->op.d.in_w;
   const long long npix = (long long)n * H * W;
-  if (npix * zs * 4 > 0xFFFFFFF0ll || npix > 0x7FFFFFFFll) return -4;   // buffer-descriptor range of the helper GEMM
+  if (npix * zs * 4 > 0xFFFFFFF0ll || npix > 0x7FFFFFFFll) return -4;   // buffer-descriptor range of the helper GEMMs
   if (!l0->h6_helper) {
     ian_op_desc d;
     memset(&d, 0, sizeof d);
     d.kind = IAN_OP_DENSE; d.cin = 128; d.cout = nout; d.in_h = d.in_w = 1; d.src2 = d.src3 = -1;
     int rc = ian_layer_create(&d, 1, &l0->h6_helper);
-    if (rc) return lfail(l0, rc, "head6 backward-weight: helper layer creation failed (%d)", rc);
+    if (rc) return lfail(l0, rc, "head6 backward: helper layer creation failed (%d)", rc);
     std::vector<int> tp(ntaps);
     for (int t = 0; t < ntaps; ++t) tp[t] = (L.taps[t].dy + 64) | ((L.taps[t].dx + 64) << 8);
     if ((rc = upload(&l0->ctx, tp, &l0->h6_taps))) return rc;
-    LHIP(l0, hipMalloc((void**)&l0->h6_dW, (size_t)128 * nout * sizeof(float)));
+    LHIP(l0, hipMalloc((void**)&l0->h6_dW, (size_t)2 * 128 * nout * sizeof(float)));   // [0]: dW of the helper, [1]: its W
   }
   const size_t need = (size_t)npix * zs;
   if (need > l0->h6_Z_cap) {
@@ -2694,8 +2697,19 @@ int ian_layer_head6_backward_weight(ian_layer* l0, ian_layer* l1, ian_layer* l2,
     l0->h6_Z_cap = need;
   }
   LHIP(l0, launch_head6_zbuild(dy0, dy1, dy2, dy_stride, l0->h6_Z, zs, H, W, ntaps, l0->h6_taps, npix, st));
+  int rc;
+  if (dx) {  // dx[q][c] = sum_j Z[q][j] * Wcat[c][j], Wcat[c][(t,k,f)] = slab_k[t][f][c]: the helper's backward-data GEMM
+    float* wcat = l0->h6_dW + (size_t)128 * nout;
+    for (int k = 0; k < 3; ++k)
+      LHIP(l0, launch_head6_wcat(ls[k]->op.fwd.d_w, ls[k]->op.fwd.CoutPad, ls[k]->op.fwd.Cin, k, ntaps, wcat, nout, st));
+    float* wp[1] = {wcat};
+    if ((rc = ian_layer_set_params(l0->h6_helper, wp, 1, stream)) ||
+        (rc = ian_layer_backward_data(l0->h6_helper, l0->h6_Z, (int32_t)npix, dx, dx_stride, dx_accumulate, stream)))
+      return lfail(l0, rc, "head6 backward-data GEMM: %s", ian_layer_last_error(l0->h6_helper));
+  }
+  if (!want_w) return 0;
   float* dw_ptr[1] = {l0->h6_dW};
-  int rc = ian_layer_backward_weight(l0->h6_helper, x, l0->h6_Z, (int32_t)npix, dw_ptr, 1, 0, stream);
+  rc = ian_layer_backward_weight(l0->h6_helper, x, l0->h6_Z, (int32_t)npix, dw_ptr, 1, 0, stream);
   if (rc) return lfail(l0, rc, "head6 backward-weight GEMM: %s", ian_layer_last_error(l0->h6_helper));
   for (int k = 0; k < 3; ++k) {
     ian_layer* l = ls[k];

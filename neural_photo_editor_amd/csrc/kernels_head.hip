@@ -367,6 +367,19 @@ hipError_t launch_head6_dS_scatter(const float* dWref, int nout, int kk, int nta
   return hipGetLastError();
 }
 
+// layer k's forward slab [t][f_rows][f_cols] -> the helper dense layer's reference weight Wcat[c][j], j = t*6 + 2k + f
+__global__ __launch_bounds__(256) void head6_wcat_kernel(const float* __restrict__ slab, int f_rows, int f_cols, int kk, int ntaps,
+                                                         float* __restrict__ wcat, int nout) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ntaps * 2 * 128) return;
+  const int c = i % 128, f = (i / 128) & 1, t = i / 256;
+  wcat[(size_t)c * nout + t * 6 + 2 * kk + f] = slab[((size_t)t * f_rows + f) * f_cols + c];
+}
+hipError_t launch_head6_wcat(const float* slab, int f_rows, int f_cols, int kk, int ntaps, float* wcat, int nout, hipStream_t s) {
+  hipLaunchKernelGGL(head6_wcat_kernel, dim3((ntaps * 256 + 255) / 256), dim3(256), 0, s, slab, f_rows, f_cols, kk, ntaps, wcat, nout);
+  return hipGetLastError();
+}
+
 hipError_t launch_head_tail(const HeadTailArgs& a, int n, hipStream_t s) {
   if (a.ntaps > 48 || a.H * a.W > 4096) return hipErrorInvalidValue;
   const size_t lds = (size_t)(a.H * a.W * 6 + a.ntaps * 12) * sizeof(float);

@@ -174,12 +174,14 @@ class Layer:
         self._chk(rc)
         return True
 
-    def head6_backward_weight(self, l1, l2, x, dys, n, dy_stride, dparams3, accumulate=False, stream=0):
-        """Backward-weight of the same three layers as ONE dense contraction (ian_layer_head6_backward_weight); False when the
-        shape does not qualify."""
-        rc = self.lib.ian_layer_head6_backward_weight(self.h, l1.h, l2.h, _p(x), _p(dys[0]), _p(dys[1]), _p(dys[2]), n, dy_stride,
-                                                      self._ptrs(dparams3[0]), self._ptrs(dparams3[1]), self._ptrs(dparams3[2]),
-                                                      len(dparams3[0]), int(accumulate), C.c_void_p(stream))
+    def head6_backward(self, l1, l2, x, dys, n, dy_stride, dx=None, dx_stride=0, dx_accumulate=False, dparams3=None, accumulate=False,
+                       stream=0):
+        """Backward of the same three layers through one shifted gather + dense GEMMs (ian_layer_head6_backward): data gradient
+        into dx and/or weight gradients into dparams3 = [[5 tensors] x 3]; False when the shape does not qualify."""
+        pp = [self._ptrs(d) for d in dparams3] if dparams3 else [None, None, None]
+        rc = self.lib.ian_layer_head6_backward(self.h, l1.h, l2.h, _p(x), _p(dys[0]), _p(dys[1]), _p(dys[2]), n, dy_stride, _p(dx),
+                                               dx_stride, int(dx_accumulate), pp[0], pp[1], pp[2], len(dparams3[0]) if dparams3 else 0,
+                                               int(accumulate), C.c_void_p(stream))
         if rc == -4:
             return False
         self._chk(rc)
@@ -501,18 +503,23 @@ class Trainer:
         layer.backward_weight(x, dy, n, [self.G(p) for p in pnames], accumulate=acc)
         self.touched.update(pnames)
 
-    def _wgrad_head(self, x, dR, dG, dB, n):
-        """R / G_a / B_a weight gradients (IAN.py:183-199): one contract-first pass, or the three separate calls."""
+    def _head_backward(self, x, dR, dG, dB, n, dx, want_w):
+        """Backward of R / G_a / B_a (IAN.py:183-199) once all three seeds are final: dx = sum of the three data gradients,
+        plus the weight gradients -- one contract-first pass, or the per-layer calls."""
         names = ("R", "G_a", "B_a")
         ls = [self.layers[nm] for nm in names]
         accs = [pn[0] in self.touched for _, pn in ls]
-        if self.head6 and len(set(accs)) == 1 and ls[0][0].head6_backward_weight(
-                ls[1][0], ls[2][0], x, (dR, dG, dB), n, 32, [[self.G(p) for p in pn] for _, pn in ls], accumulate=accs[0]):
-            for _, pn in ls:
-                self.touched.update(pn)
+        if self.head6 and len(set(accs)) == 1 and ls[0][0].head6_backward(
+                ls[1][0], ls[2][0], x, (dR, dG, dB), n, 32, dx=dx, dx_stride=128,
+                dparams3=[[self.G(p) for p in pn] for _, pn in ls] if want_w else None, accumulate=accs[0]):
+            if want_w:
+                for _, pn in ls:
+                    self.touched.update(pn)
             return
-        for nm, dy in zip(names, (dR, dG, dB)):
-            self._wgrad(nm, x, dy, n)
+        for i, (nm, dy) in enumerate(zip(names, (dR, dG, dB))):
+            if want_w:
+                self._wgrad(nm, x, dy, n)
+            self.layers[nm][0].backward_data(dy, n, dx, accumulate=i > 0)
 
     # ---------------------------------------------------------------------------------------------
     # encoder pass (IAN.py:71-110 + discriminator head :209-216), training mode
@@ -708,7 +715,6 @@ class Trainer:
         if want_w:
             self._wgrad("B_b", D["RG"], D["gB"], n)
         lay("B_b").backward_data(D["gB"], n, D["dRG"])
-        lay("B_a").backward_data(D["gB"], n, D["dh4"])
         k.grad_pass(D["dRG"], 32, 0, D["gR"], D["R"], 32, rows, 2, sg, 1)
         k.grad_pass(D["dRG"], 32, 2, D["gG"], D["G"], 32, rows, 2, sg, 1)
         # G = sigmoid(G_a(h4) + G_b(R))
@@ -716,11 +722,8 @@ class Trainer:
             self._wgrad("G_b", D["R"], D["gG"], n)
         lay("G_b").backward_data(D["gG"], n, D["dRt"])
         k.grad_pass(D["dRt"], 32, 0, D["gR"], D["R"], 32, rows, 2, sg, 1)
-        lay("G_a").backward_data(D["gG"], n, D["dh4"], accumulate=True)
         # R = sigmoid(R(h4))
-        if want_w:
-            self._wgrad_head(D["h4"], D["gR"], D["gG"], D["gB"], n)      # all three seeds are final here
-        lay("R").backward_data(D["gR"], n, D["dh4"], accumulate=True)
+        self._head_backward(D["h4"], D["gR"], D["gG"], D["gB"], n, D["dh4"], want_w)      # all three seeds are final here
         # dec_conv4 + bnorm_dc4 + lrelu
         self._bn_backward(D["bn4"], D["dh4"], D["h4"], D["y4"], D["dh4"], rows, 128, 128, ACT["lrelu"], "bnorm_dc4.gamma", "bnorm_dc4.beta", want_w)
         prev_h = D[DEC_STAGES[-1][4] + "_h"]

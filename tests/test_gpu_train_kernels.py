@@ -377,44 +377,58 @@ def test_head6_forward_equals_three_layer_forwards(env, n):
 
 
 @pytest.mark.parametrize("n,accumulate", [(2, False), (5, True)])
-def test_head6_backward_weight_equals_three_layer_calls(env, n, accumulate):
-    """ian_layer_head6_backward_weight (one dense contraction for R, G_a, B_a) vs the three ian_layer_backward_weight calls and
-    vs float64 autograd of the layer expression (IAN.py:183-199; MDCL W + per-dilation coefficients)."""
+def test_head6_backward_equals_three_layer_calls(env, n, accumulate):
+    """ian_layer_head6_backward (one shifted gather + two dense GEMMs for R, G_a, B_a) vs the three ian_layer_backward_weight /
+    ian_layer_backward_data calls and vs float64 autograd of the layer expression (IAN.py:183-199; MDCL W + coefficients)."""
     lib, T, k = env
     rs = np.random.RandomState(23 + n)
     sc = [2, 3, 4]
     x = rs.randn(n, 128, 64, 64).astype(np.float32)
     xd = to_nhwc(x)
     layers, keep, refs, dys = [], [], [], []
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    total = 0.0
+    leaves = []
     for i in range(3):
         W = (rs.randn(2, 128, 3, 3) * 0.05).astype(np.float32)
         coeffs = [rs.uniform(0.5, 1.5, 2).astype(np.float32) for _ in range(4)]
         dy = rs.randn(n, 2, 64, 64).astype(np.float32)
-        xt = torch.tensor(x, dtype=torch.float64)
         Wt = torch.tensor(W, dtype=torch.float64, requires_grad=True)
         ct = [torch.tensor(c, dtype=torch.float64, requires_grad=True) for c in coeffs]
         y = F.conv2d(xt, Wt, padding=1) * ct[0].reshape(1, -1, 1, 1)
         for j, s in enumerate(sc):
             y = y + F.conv2d(xt, Wt, padding=s, dilation=s) * ct[1 + j].reshape(1, -1, 1, 1)
-        (y * torch.tensor(dy, dtype=torch.float64)).sum().backward()
-        refs.append([Wt.grad.numpy().ravel()] + [c.grad.numpy() for c in ct])
+        total = total + (y * torch.tensor(dy, dtype=torch.float64)).sum()
+        leaves.append([Wt] + ct)
         layer = T.Layer(lib, T.K_MDC, 128, 2, 64, 64, scales=sc)
         params = [torch.from_numpy(a.ravel()).cuda() for a in [W] + coeffs]
         keep.append(params)
         layer.set_params(params)
         layers.append(layer)
         dys.append(to_nhwc(dy))
+    total.backward()
+    refs = [[t.grad.numpy().ravel() for t in lv] for lv in leaves]
     base = 0.25 if accumulate else 0.0
     fused = [[torch.full_like(p, base) for p in ps] for ps in keep]
-    assert layers[0].head6_backward_weight(layers[1], layers[2], xd, dys, n, 32, fused, accumulate=accumulate)
+    dx_f = torch.full((n, 64, 64, 128), base, device="cuda")
+    assert layers[0].head6_backward(layers[1], layers[2], xd, dys, n, 32, dx=dx_f, dx_stride=128, dx_accumulate=accumulate,
+                                    dparams3=fused, accumulate=accumulate)
     sep = [[torch.full_like(p, base) for p in ps] for ps in keep]
+    dx_s = torch.full((n, 64, 64, 128), base, device="cuda")
     for i in range(3):
         layers[i].backward_weight(xd, dys[i], n, sep[i], accumulate=accumulate)
+        layers[i].backward_data(dys[i], n, dx_s, accumulate=accumulate or i > 0)
     torch.cuda.synchronize()
     for i in range(3):
         for j in range(5):
             got, two, ref = fused[i][j].cpu().numpy() - base, sep[i][j].cpu().numpy() - base, refs[i][j]
             assert rel(got, ref) < TOL, (i, j)
             assert rel(got, two) < 1e-5, (i, j)
+    assert rel(from_nhwc(dx_f, 128) - base, xt.grad.numpy()) < TOL
+    assert rel(from_nhwc(dx_f, 128), from_nhwc(dx_s, 128)) < 1e-5
+    # data gradient alone (no x, no parameter gradients)
+    dx_o = torch.zeros(n, 64, 64, 128, device="cuda")
+    assert layers[0].head6_backward(layers[1], layers[2], None, dys, n, 32, dx=dx_o, dx_stride=128)
+    assert rel(from_nhwc(dx_o, 128), xt.grad.numpy()) < TOL
     for l in layers:
         l.close()
