@@ -290,6 +290,16 @@ def main():
                 z = z - 0.05 * g * (1 + (c2 - c1))
                 model.photo_blend(z, RECON, ERROR)
                 lat3.append((time.perf_counter() - t) * 1e3)
+            # the whole brush event as ONE submission (ian_brush_step: gradient + latent update + decoder, one sync)
+            lat5, lat6 = [], []
+            for i in range(100):
+                t = time.perf_counter()
+                z, _ = model.brush_step(c1, r1, c2, r2, z, RGB=rgb, weight=0.05)
+                lat5.append((time.perf_counter() - t) * 1e3)
+            for i in range(80):
+                t = time.perf_counter()
+                z = model.brush_step(c1, r1, c2, r2, z, RGB=rgb, weight=0.05, image=False, photo=(RECON, ERROR))[0]
+                lat6.append((time.perf_counter() - t) * 1e3)
             h.set_option("edit_graph", 0)       # the same loop with eager launches (round-1 behaviour) for comparison
             lat4 = []
             for i in range(60):
@@ -303,10 +313,13 @@ def main():
                     "p50_ms_no_forward_cache": float(np.percentile(lat2[10:], 50)),
                     "p50_ms_eager_launches": float(np.percentile(lat4[10:], 50)),
                     "p50_ms_photo_mode": float(np.percentile(lat3[20:], 50)),
+                    "p50_ms_one_call": float(np.percentile(lat5[20:], 50)), "p95_ms_one_call": float(np.percentile(lat5[20:], 95)),
+                    "p50_ms_one_call_photo_mode": float(np.percentile(lat6[20:], 50)),
                     "update": "gradient descent (reference, NPE.py:199-209)",
                     "calls": "imgradRGB + sample_at through the API.py surface (host numpy in/out); batch-1 host calls replay captured "
                              "hipGraphs on an internal stream; imgradRGB reuses the decoder activations sample_at left for the same "
-                             "latent; photo mode = imgradRGB + the device blend of NPE.py:218-231 (12 KB uint8 image back)",
+                             "latent; photo mode = imgradRGB + the device blend of NPE.py:218-231 (12 KB uint8 image back); "
+                             "one_call = ian_brush_step: gradient + latent update + decoder (+ blend) in one graph replay, one sync",
                     "includes": "host<->device copies of z, rgb, image"}
         host_io = None
         if args.host_io:

@@ -148,6 +148,28 @@ int ian_decode_u8(ian_handle* h, const float* z, int32_t n, uint8_t* out, void* 
 int ian_photo_blend(ian_handle* h, const float* z, const uint8_t* recon, const float* error, const double* gauss_half,
                     int32_t radius, uint8_t* im, double* mask, void* stream);
 
+/* One whole brush event of NPE.paint / NPE.scroll (NPE.py:199-218, 305-316) in ONE call, one graph replay, one
+   synchronisation -- instead of imgradRGB + host update + sample_at (two round trips):
+     dZ    = rgb ? imgradRGB(c1,r1,c2,r2, rgb, z) : imgrad(c1,r1,c2,r2, z)        (API.py:66-76)
+     z_new = z + coef * (dZ * gscale)        float32, each product rounded on its own, in this order -- NPE.py:205-209
+             "grad = temp*(1+(x2-x1)); Z -= weight*grad" is coef = -weight, gscale = 1+(x2-x1); NPE.py:313-314 is
+             coef = sign*weight -- bit-identical to the numpy expression on a float32 Z
+     x     = sample_at(z_new)                                                       (API.py:98-110)
+   z, z_new f32[num_latents] (host; may alias), dz f32[num_latents] or NULL, x f32[3,64,64] or NULL (the decoder runs either
+   way: its activations stay resident for the next event), photo = NULL or the arguments of ian_photo_blend, applied to
+   sample_at(z_new) in the same submission (photo mode, NPE.py:218-231).  rgb f32[1,3,64,64] host or device.
+   Falls back to the composition of the public calls when the captured-graph path is not available. */
+typedef struct ian_photo_args {
+  const uint8_t* recon;       /* u8[3,64,64] */
+  const float* error;         /* f32[3,64,64] */
+  const double* gauss_half;   /* f64[radius+1] */
+  int32_t radius;
+  uint8_t* im;                /* out u8[3,64,64] */
+  double* mask;               /* out f64[64,64] or NULL */
+} ian_photo_args;
+int ian_brush_step(ian_handle* h, int32_t c1, int32_t r1, int32_t c2, int32_t r2, const float* rgb, const float* z, float coef,
+                   float gscale, float* z_new, float* dz, float* x, const ian_photo_args* photo, void* stream);
+
 /* Introspection used by tests, bench.py and profiling (not part of the reference surface). */
 /* Copy the activation of tensor slot `slot` from the last call, converted to NCHW, into out (host or device). */
 int ian_read_slot(ian_handle* h, int32_t slot, int32_t n, float* out, void* stream);

@@ -135,6 +135,33 @@ class IAN:
         self._h.photo_blend(z[:1], recon, err, half, im, mask)
         return im, mask
 
+    def brush_step(self, c1, r1, c2, r2, z, RGB=None, weight=0.05, sign=-1.0, image=True, photo=None, sigma=0.7, want_mask=False):
+        """One whole NPE.paint / NPE.scroll event on the device (ian_brush_step): the latent gradient (imgradRGB when RGB is
+        given, imgrad otherwise), Z + sign*weight*(dZ*(1+(c2-c1))) in float32 exactly as NPE.py:205-209 / 313-314 compute it,
+        and sample_at of the new latent -- one submission instead of two calls with a host update between them.
+        -> (z_new (1,zdim), image (1,3,64,64) or None)  or, with photo=(RECON uint8, ERROR float32),
+           (z_new, image or None, IM uint8 (3,64,64), MASK float64 (64,64) if want_mask else None)  (photo mode,
+           NPE.py:218-231; NPE.paint itself only displays IM, so the 32 KB mask stays on the device unless asked for)."""
+        from . import npe_ops
+        z = self._f32(z, (self._zdim,), "z")
+        rgb = self._f32(RGB, (3, 64, 64), "RGB")[:1] if RGB is not None else None
+        z_new = np.empty((1, self._zdim), np.float32)
+        x = np.empty((1, 3, 64, 64), np.float32) if image else None
+        pa = None
+        if photo is not None:
+            recon = np.ascontiguousarray(photo[0], dtype=np.uint8)
+            err = np.ascontiguousarray(photo[1], dtype=np.float32)
+            if recon.shape != (3, 64, 64) or err.shape != (3, 64, 64):
+                raise ValueError("RECON and ERROR must have shape (3,64,64)")
+            half = npe_ops.gaussian_half_kernel(sigma, int(4.0 * float(sigma) + 0.5))
+            im, mask = np.empty((3, 64, 64), np.uint8), (np.empty((64, 64), np.float64) if want_mask else None)
+            pa = (recon, err, half, im, mask)
+        coef = float(sign) * float(weight)      # rounded to float32 at the boundary, as numpy rounds the scalar
+        self._h.brush_step(int(c1), int(r1), int(c2), int(r2), rgb, z[:1], coef, float(1 + (int(c2) - int(c1))), z_new, None, x, pa)
+        if photo is not None:
+            return z_new, x, pa[3], pa[4]
+        return z_new, x
+
     # ---- sample_IAN.py function equivalents (SURVEY M3) ----------------------------------------------
     def sampleZ(self, z):
         """sample_IAN.py:88: l_Z -> l_out (same as sample_at)."""

@@ -222,6 +222,7 @@ struct PhotoBlendArgs {
   int radius;
 };
 hipError_t launch_photo_blend(const PhotoBlendArgs& a, hipStream_t s);
+hipError_t launch_latent_update(float* z, const float* g, const float* cg, int n, hipStream_t s);
 hipError_t launch_to_uint8(const float* x, unsigned char* y, long long n, hipStream_t s);
 
 // identity-edge gradient hand-over: gd[p,c] (+)= gs[p,coff+c] * act'(y[p,c]) * scale[c]   (NHWC, strides ss / ds)

@@ -183,7 +183,7 @@ struct ian_handle {
   hipStream_t edit_stream = nullptr;
   float* pin = nullptr;      // pinned host block: z [0,128) | dz [128,256) | image [256, 256+12288) | patch (4 ints) after that
   int* d_patch = nullptr;
-  EditGraph g_fwd, g_bwd[2];
+  EditGraph g_fwd, g_bwd[2], g_step[2][2];   // g_step[mode][image wanted]: backward + latent update + forward (ian_brush_step)
   bool graph_failed = false;
   hipStream_t last_stream = nullptr;   // stream of the last call that left work un-synchronised (or nullptr)
   bool last_pending = false;
@@ -1542,7 +1542,7 @@ int edit_ctx(ian_handle* h) {
   if (h->edit_stream) return 0;
   HIPCHK(h, hipStreamCreateWithFlags(&h->edit_stream, hipStreamNonBlocking));
   HIPCHK(h, hipHostMalloc((void**)&h->pin, PIN_FLOATS * sizeof(float), hipHostMallocDefault));
-  HIPCHK(h, hipMalloc((void**)&h->d_patch, 4 * sizeof(int)));
+  HIPCHK(h, hipMalloc((void**)&h->d_patch, 8 * sizeof(int)));   // brush rectangle + (coef, gscale) of ian_brush_step
   if (128 > h->stage_in_cap) {
     if (h->d_stage_in) HIPCHK(h, hipFree(h->d_stage_in));
     HIPCHK(h, hipMalloc((void**)&h->d_stage_in, 128 * sizeof(float)));
@@ -1726,6 +1726,51 @@ int grad_common(ian_handle* h, int mode, int c1, int r1, int c2, int r2, const f
   }
   return 0;
 }
+
+// NPE.py:218-231 for the image resident in the output slot: (cached) uploads of RECON / ERROR, the blend kernel, copies
+// back.  *pending = a host copy was enqueued (the caller synchronises).
+int enqueue_photo_blend(ian_handle* h, const uint8_t* recon, const float* error, const double* gauss_half, int radius, uint8_t* im,
+                        double* mask, hipStream_t st, bool* pending) {
+  if (!recon || !error || !gauss_half || !im) return fail(h, -1, "null pointer passed to the photo blend");
+  if (radius < 0 || radius > 7) return fail(h, -7, "photo blend: radius %d outside 0..7", radius);
+  Slot& os = h->slots[h->desc.out_slot];
+  if (os.h != 64 || os.w != 64 || os.c != 3) return fail(h, -7, "the photo blend needs a 3x64x64 image");
+  const size_t cnt = 3 * 64 * 64;
+  PhotoBlendArgs a;
+  memset(&a, 0, sizeof a);
+  a.xhat = os.d;
+  if (is_device_ptr(recon)) a.recon = recon;
+  else {
+    if (!h->d_recon) HIPCHK(h, hipMalloc((void**)&h->d_recon, cnt));
+    if (h->recon_cache.size() != cnt || memcmp(h->recon_cache.data(), recon, cnt) != 0) {   // changes on infer / Reset only
+      h->recon_cache.assign(recon, recon + cnt);
+      HIPCHK(h, hipMemcpyAsync(h->d_recon, h->recon_cache.data(), cnt, hipMemcpyHostToDevice, st));
+    }
+    a.recon = h->d_recon;
+  }
+  if (is_device_ptr(error)) a.error = error;
+  else {
+    if (!h->d_error) HIPCHK(h, hipMalloc((void**)&h->d_error, cnt * sizeof(float)));
+    if (h->error_cache.size() != cnt || memcmp(h->error_cache.data(), error, cnt * sizeof(float)) != 0) {
+      h->error_cache.assign(error, error + cnt);
+      HIPCHK(h, hipMemcpyAsync(h->d_error, h->error_cache.data(), cnt * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    a.error = h->d_error;
+  }
+  const bool im_dev = is_device_ptr(im), mask_dev = mask && is_device_ptr(mask);
+  if (!im_dev && !h->d_im) HIPCHK(h, hipMalloc((void**)&h->d_im, cnt));
+  if (mask && !mask_dev && !h->d_mask) HIPCHK(h, hipMalloc((void**)&h->d_mask, 64 * 64 * sizeof(double)));
+  a.im = im_dev ? im : h->d_im;
+  a.mask = mask ? (mask_dev ? mask : h->d_mask) : nullptr;
+  for (int i = 0; i <= radius; ++i) a.w[i] = gauss_half[i];
+  a.radius = radius;
+  HIPCHK(h, launch_photo_blend(a, st));
+  if (!im_dev) HIPCHK(h, hipMemcpyAsync(im, h->d_im, cnt, hipMemcpyDeviceToHost, st));
+  if (mask && !mask_dev) HIPCHK(h, hipMemcpyAsync(mask, h->d_mask, 64 * 64 * sizeof(double), hipMemcpyDeviceToHost, st));
+  *pending = !im_dev || (mask && !mask_dev);
+  return 0;
+}
+
 
 }  // namespace
 
@@ -1980,42 +2025,86 @@ int ian_photo_blend(ian_handle* h, const float* z, const uint8_t* recon, const f
   if (graph) {
     if ((rc = decode_one_graph(h, z))) return rc;
   } else if ((rc = decode_one_cached(h, z, st))) return rc;
-  const size_t cnt = 3 * 64 * 64;
-  PhotoBlendArgs a;
-  memset(&a, 0, sizeof a);
-  a.xhat = os.d;
-  if (is_device_ptr(recon)) a.recon = recon;
-  else {
-    if (!h->d_recon) HIPCHK(h, hipMalloc((void**)&h->d_recon, cnt));
-    if (h->recon_cache.size() != cnt || memcmp(h->recon_cache.data(), recon, cnt) != 0) {   // changes on infer / Reset only
-      h->recon_cache.assign(recon, recon + cnt);
-      HIPCHK(h, hipMemcpyAsync(h->d_recon, h->recon_cache.data(), cnt, hipMemcpyHostToDevice, st));
-    }
-    a.recon = h->d_recon;
-  }
-  if (is_device_ptr(error)) a.error = error;
-  else {
-    if (!h->d_error) HIPCHK(h, hipMalloc((void**)&h->d_error, cnt * sizeof(float)));
-    if (h->error_cache.size() != cnt || memcmp(h->error_cache.data(), error, cnt * sizeof(float)) != 0) {
-      h->error_cache.assign(error, error + cnt);
-      HIPCHK(h, hipMemcpyAsync(h->d_error, h->error_cache.data(), cnt * sizeof(float), hipMemcpyHostToDevice, st));
-    }
-    a.error = h->d_error;
-  }
-  const bool im_dev = is_device_ptr(im), mask_dev = mask && is_device_ptr(mask);
-  if (!im_dev && !h->d_im) HIPCHK(h, hipMalloc((void**)&h->d_im, cnt));
-  if (mask && !mask_dev && !h->d_mask) HIPCHK(h, hipMalloc((void**)&h->d_mask, 64 * 64 * sizeof(double)));
-  a.im = im_dev ? im : h->d_im;
-  a.mask = mask ? (mask_dev ? mask : h->d_mask) : nullptr;
-  for (int i = 0; i <= radius; ++i) a.w[i] = gauss_half[i];
-  a.radius = radius;
-  HIPCHK(h, launch_photo_blend(a, st));
-  if (!im_dev) HIPCHK(h, hipMemcpyAsync(im, h->d_im, cnt, hipMemcpyDeviceToHost, st));
-  if (mask && !mask_dev) HIPCHK(h, hipMemcpyAsync(mask, h->d_mask, 64 * 64 * sizeof(double), hipMemcpyDeviceToHost, st));
-  if (!im_dev || (mask && !mask_dev)) {
+  bool pending = false;
+  if ((rc = enqueue_photo_blend(h, recon, error, gauss_half, radius, im, mask, st, &pending))) return rc;
+  if (pending) {
     HIPCHK(h, hipStreamSynchronize(st));
     h->last_pending = false;
   }
+  return 0;
+}
+
+int ian_brush_step(ian_handle* h, int32_t c1, int32_t r1, int32_t c2, int32_t r2, const float* rgb, const float* z, float coef,
+                   float gscale, float* z_new, float* dz, float* x, const ian_photo_args* photo, void* stream) {
+  int rc = check_ready(h, 1);
+  if (rc) return rc;
+  if (!z || !z_new) return fail(h, -1, "null pointer passed to ian_brush_step");
+  for (const void* p : {(const void*)z, (const void*)z_new, (const void*)dz, (const void*)x})
+    if (p && is_device_ptr(p)) return fail(h, -7, "ian_brush_step takes host buffers for z, z_new, dz, x (the Tk callback's arrays)");
+  const int mode = rgb ? 1 : 0;
+  const int zl = h->desc.num_latents;
+  Slot& zs = h->slots[h->desc.z_slot];
+  Slot& out = h->slots[h->desc.out_slot];
+  if (c1 < 0 || r1 < 0 || c2 > out.w || r2 > out.h) return fail(h, -7, "patch (%d,%d,%d,%d) outside the %dx%d image", c1, r1, c2, r2, out.w, out.h);
+  const bool photo_host = photo && !is_device_ptr(photo->recon) && !is_device_ptr(photo->error) && !is_device_ptr(photo->im) &&
+                          !(photo->mask && is_device_ptr(photo->mask));
+  if (!edit_graph_eligible(h, stream, {rgb}) || (photo && !photo_host)) {
+    // the same step composed from the public calls (profiling on, a caller stream, graphs switched off, ...)
+    std::vector<float> g((size_t)std::max(zs.c, zl)), zn((size_t)zl);
+    if ((rc = grad_common(h, mode, c1, r1, c2, r2, rgb, z, g.data(), stream))) return rc;
+    for (int i = 0; i < zl; ++i) {
+      volatile float t = g[i] * gscale;   // volatile: one rounding per operation, as numpy does it
+      volatile float u = coef * t;
+      zn[i] = z[i] + u;
+    }
+    if (dz) memcpy(dz, g.data(), zl * sizeof(float));
+    if (x) {
+      if ((rc = ian_decode(h, zn.data(), 1, x, stream))) return rc;
+    } else if (!photo) {
+      hipStream_t st = (hipStream_t)stream;
+      enter_stream(h, st);
+      if ((rc = decode_one_cached(h, zn.data(), st))) return rc;
+    }
+    if (photo && (rc = ian_photo_blend(h, zn.data(), photo->recon, photo->error, photo->gauss_half, photo->radius, photo->im, photo->mask, stream)))
+      return rc;
+    memcpy(z_new, zn.data(), zl * sizeof(float));
+    return 0;
+  }
+  if ((rc = edit_ctx(h))) return rc;
+  hipStream_t st = h->edit_stream;
+  enter_stream(h, st);
+  if ((rc = decode_one_graph(h, z))) return rc;   // no-op when the resident activations already belong to z
+  const float* d_rgb = nullptr;
+  if (mode == 1 && (rc = upload_rgb_if_changed(h, rgb, st, &d_rgb))) return rc;
+  if ((rc = ensure_slot(h, h->desc.z_slot, 1, true))) return rc;
+  int* patch = reinterpret_cast<int*>(h->pin + PIN_IMG + 3 * 64 * 64);
+  patch[0] = c1; patch[1] = r1; patch[2] = c2; patch[3] = r2;
+  memcpy(patch + 4, &coef, sizeof(float));
+  memcpy(patch + 5, &gscale, sizeof(float));
+  h->dec_cache_valid = false;
+  const int wx = x ? 1 : 0;
+  rc = run_or_replay(h, h->g_step[mode][wx], [&]() -> int {
+    HIPCHK(h, hipMemcpyAsync(h->d_patch, patch, 6 * sizeof(int), hipMemcpyHostToDevice, st));
+    int r = run_decoder_backward(h, mode, 0, 0, out.w, out.h, d_rgb, st, h->d_patch);
+    if (r) return r;
+    HIPCHK(h, hipMemcpyAsync(h->pin + PIN_DZ, zs.g, zs.c * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, launch_latent_update(zs.d, zs.g, reinterpret_cast<const float*>(h->d_patch + 4), zl, st));
+    HIPCHK(h, hipMemcpyAsync(h->pin + PIN_Z, zs.d, zl * sizeof(float), hipMemcpyDeviceToHost, st));
+    if ((r = run_segment(h, IAN_SEG_DEC, 1, st))) return r;
+    if (wx) HIPCHK(h, hipMemcpyAsync(h->pin + PIN_IMG, out.d, out.per_image() * sizeof(float), hipMemcpyDeviceToHost, st));
+    return 0;
+  });
+  if (rc) return rc;
+  bool pending = false;
+  if (photo && (rc = enqueue_photo_blend(h, photo->recon, photo->error, photo->gauss_half, photo->radius, photo->im, photo->mask, st, &pending)))
+    return rc;
+  HIPCHK(h, hipStreamSynchronize(st));
+  h->last_pending = false;
+  memcpy(z_new, h->pin + PIN_Z, zl * sizeof(float));
+  if (dz) memcpy(dz, h->pin + PIN_DZ, zl * sizeof(float));
+  if (x) memcpy(x, h->pin + PIN_IMG, out.per_image() * sizeof(float));
+  h->dec_cache_z.assign(z_new, z_new + zl);
+  h->dec_cache_valid = true;
   return 0;
 }
 
@@ -2213,7 +2302,7 @@ void ian_destroy(ian_handle* h) {
   for (float* p : {h->d_slab, h->d_stage_in, h->d_stage_out, h->d_gseed, h->d_rgb, h->head.d_ftab, h->head.d_comp})
     if (p) (void)hipFree(p);
   if (h->head.d_itab) (void)hipFree(h->head.d_itab);
-  for (ian_handle::EditGraph* g : {&h->g_fwd, &h->g_bwd[0], &h->g_bwd[1]})
+  for (ian_handle::EditGraph* g : {&h->g_fwd, &h->g_bwd[0], &h->g_bwd[1], &h->g_step[0][0], &h->g_step[0][1], &h->g_step[1][0], &h->g_step[1][1]})
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
   if (h->edit_stream) (void)hipStreamDestroy(h->edit_stream);
   if (h->pin) (void)hipHostFree(h->pin);

@@ -114,6 +114,23 @@ __global__ __launch_bounds__(256) void to_uint8_kernel(const float* __restrict__
     for (long long k = i; k < n; ++k) y[k] = np_uint8f(255.0f * (x[k] + 1.0f) / 2.0f);
   }
 }
+// Z += coef * (dZ * gscale) in float32, every product rounded on its own (NPE.py:205-209: grad = temp*(1+(x2-x1));
+// Z -= weight*grad  ->  coef = -weight;  NPE.py:313-314 likewise with coef = sign*weight).  cg = {coef, gscale} in device memory
+// so that a captured graph can be replayed with other values.
+__global__ __launch_bounds__(128) void latent_update_kernel(float* __restrict__ z, const float* __restrict__ g,
+                                                            const float* __restrict__ cg, int n) {
+  const int i = threadIdx.x;
+  if (i < n) {
+    float t = g[i] * cg[1];
+    t = cg[0] * t;
+    z[i] = z[i] + t;
+  }
+}
+hipError_t launch_latent_update(float* z, const float* g, const float* cg, int n, hipStream_t s) {
+  if (n > 128) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(latent_update_kernel, dim3(1), dim3(128), 0, s, z, g, cg, n);
+  return hipGetLastError();
+}
 hipError_t launch_to_uint8(const float* x, unsigned char* y, long long n, hipStream_t s) {
   hipLaunchKernelGGL(to_uint8_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, s, x, y, n);
   return hipGetLastError();

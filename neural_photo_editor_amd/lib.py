@@ -43,7 +43,7 @@ EXPORTS = (
     "ian_create", "ian_load_param", "ian_set_made_masks", "ian_finalize", "ian_encode", "ian_decode",
     "ian_encode_pre_iaf", "ian_iaf", "ian_reconstruct", "ian_grad_rgb", "ian_grad_light", "ian_decode_u8", "ian_photo_blend",
     "ian_read_slot", "ian_read_slot_grad",
-    "ian_profile_enable", "ian_profile_read", "ian_autotune", "ian_set_option", "ian_last_error", "ian_version", "ian_destroy",
+    "ian_brush_step", "ian_profile_enable", "ian_profile_read", "ian_autotune", "ian_set_option", "ian_last_error", "ian_version", "ian_destroy",
 )
 
 _lib = None
@@ -78,6 +78,7 @@ def load_library():
     lib.ian_grad_light.argtypes = [vp, i32, i32, i32, i32, fp, fp, vp]
     lib.ian_decode_u8.argtypes = [vp, fp, i32, fp, vp]
     lib.ian_photo_blend.argtypes = [vp, fp, fp, fp, fp, i32, fp, fp, vp]
+    lib.ian_brush_step.argtypes = [vp, i32, i32, i32, i32, fp, fp, C.c_float, C.c_float, fp, fp, fp, C.POINTER(PhotoArgs), vp]
     lib.ian_read_slot.argtypes = [vp, i32, i32, fp, vp]
     lib.ian_read_slot_grad.argtypes = [vp, i32, i32, fp, vp]
     lib.ian_profile_enable.argtypes = [vp, i32]
@@ -95,6 +96,12 @@ def load_library():
             getattr(lib, fn).restype = i32
     _lib = lib
     return lib
+
+
+class PhotoArgs(C.Structure):
+    """ian_photo_args (include/ian.h)."""
+    _fields_ = [("recon", C.c_void_p), ("error", C.c_void_p), ("gauss_half", C.c_void_p), ("radius", C.c_int32),
+                ("im", C.c_void_p), ("mask", C.c_void_p)]
 
 
 class IanError(RuntimeError):
@@ -178,6 +185,18 @@ class Handle:
     def photo_blend(self, z, recon_u8, error, gauss_half, im, mask=None, stream=None):
         self._check(self.lib.ian_photo_blend(self._h, _ptr(z), _ptr(recon_u8), _ptr(error), _ptr(gauss_half), len(gauss_half) - 1,
                                              _ptr(im), _ptr(mask) if mask is not None else C.c_void_p(0), C.c_void_p(stream or 0)))
+
+    def brush_step(self, c1, r1, c2, r2, rgb, z, coef, gscale, z_new, dz=None, x=None, photo=None, stream=None):
+        """ian_brush_step; photo = (recon_u8, error, gauss_half, im, mask or None)."""
+        null = C.c_void_p(0)
+        pa = None
+        if photo is not None:
+            recon, err, half, im, mask = photo
+            pa = PhotoArgs(_ptr(recon).value, _ptr(err).value, _ptr(half).value, len(half) - 1, _ptr(im).value,
+                           _ptr(mask).value if mask is not None else None)
+        self._check(self.lib.ian_brush_step(self._h, c1, r1, c2, r2, _ptr(rgb) if rgb is not None else null, _ptr(z), coef, gscale,
+                                            _ptr(z_new), _ptr(dz) if dz is not None else null, _ptr(x) if x is not None else null,
+                                            C.byref(pa) if pa is not None else None, C.c_void_p(stream or 0)))
 
     def read_slot(self, slot, n):
         h, w, c = self.lowered.slots[slot]

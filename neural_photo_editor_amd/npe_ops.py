@@ -2,7 +2,8 @@
 the photo blend.  In the reference they are 64x64x3 numpy/scipy expressions inside the Tk callbacks; here
 
   * ``brush_step`` / ``lighten_step`` are the latent updates of NPE.paint / NPE.scroll (host arithmetic on 100 floats
-    around the HIP gradient call);
+    around the HIP gradient call); ``paint_event`` is the whole NPE.paint body as one device submission
+    (``ian_brush_step``: gradient, latent update, decoder, optional blend);
   * ``photo_blend`` is NPE.paint's photo-mode blend (NPE.py:218-231).  With a ``neural_photo_editor_amd.IAN`` model it
     runs as ONE 64x64 HIP kernel chained after the decoder (``ian_photo_blend``, include/ian.h): the decoded image never
     leaves the device, the edit needs one 12 KB uint8 device->host copy;
@@ -71,22 +72,46 @@ def photo_blend_host(xhat, recon_uint8, error):
 
 
 def brush_step(model, Z, box, rgb_uint8, weight=0.05):
-    """NPE.paint's latent update (NPE.py:199-209): Z -= weight * dL/dZ * (1 + (x2 - x1)).
+    """NPE.paint's latent update (NPE.py:199-209), in the reference's order on a float32 Z:
+    grad = dL/dZ * (1 + (x2 - x1));  Z -= weight * grad.
     Z: (10,10) or (1,100) float32; box = (x1, y1, x2, y2) in 64-pixel space; rgb_uint8: (3,64,64) brush colour image."""
     x1, y1, x2, y2 = [int(v) for v in box]
     shape = np.shape(Z)
     z = np.float32(np.reshape(Z, (1, -1)))
     g = np.asarray(model.imgradRGB(x1, y1, x2, y2, np.float32(to_tanh(np.float32(rgb_uint8)))[None], z)[0])
-    return (z[0] - weight * g * (1 + (x2 - x1))).reshape(shape).astype(np.float32)
+    grad = g * np.float32(1 + (x2 - x1))
+    return (z[0] - np.float32(weight) * grad).reshape(shape).astype(np.float32)
 
 
 def lighten_step(model, Z, box, weight=0.1, sign=1.0):
-    """NPE.scroll (NPE.py:305-314): Z += sign(event.delta) * weight * d mean(patch)/dZ * (1 + (x2 - x1))."""
+    """NPE.scroll (NPE.py:305-314): grad = d mean(patch)/dZ * (1 + (x2 - x1));  Z += sign(event.delta) * weight * grad."""
     x1, y1, x2, y2 = [int(v) for v in box]
     shape = np.shape(Z)
     z = np.float32(np.reshape(Z, (1, -1)))
-    g = np.asarray(model.imgrad(x1, y1, x2, y2, z)[0]) * (1 + (x2 - x1))
-    return (z[0] + sign * weight * g).reshape(shape).astype(np.float32)
+    grad = np.asarray(model.imgrad(x1, y1, x2, y2, z)[0]) * np.float32(1 + (x2 - x1))
+    return (z[0] + np.float32(float(sign) * float(weight)) * grad).reshape(shape).astype(np.float32)
+
+
+def paint_event(model, Z, box, rgb_uint8, recon_uint8=None, error=None, weight=0.05):
+    """The whole body of NPE.paint (NPE.py:199-231) for a float32 Z: brush step, then the sample (sample mode) or the blended
+    photo (photo mode, when RECON / ERROR are given).  With the HIP model this is ONE device submission
+    (``IAN.brush_step`` -> ian_brush_step); otherwise the composition of the calls above.
+    -> (Z_new in Z's shape, image): image = float32 (3,64,64) sample in sample mode, uint8 (3,64,64) IM in photo mode."""
+    x1, y1, x2, y2 = [int(v) for v in box]
+    shape = np.shape(Z)
+    z = np.float32(np.reshape(Z, (1, -1)))
+    photo = (recon_uint8, error) if recon_uint8 is not None else None
+    if hasattr(model, "brush_step"):
+        rgb = np.float32(to_tanh(np.float32(rgb_uint8)))[None]
+        if photo is None:
+            z_new, x = model.brush_step(x1, y1, x2, y2, z, RGB=rgb, weight=weight)
+            return z_new.reshape(shape), x[0]
+        z_new, _, im, _ = model.brush_step(x1, y1, x2, y2, z, RGB=rgb, weight=weight, image=False, photo=photo)
+        return z_new.reshape(shape), im
+    z_new = brush_step(model, z, box, rgb_uint8, weight)
+    if photo is None:
+        return z_new.reshape(shape), model.sample_at(z_new)[0]
+    return z_new.reshape(shape), photo_blend(model, z_new, recon_uint8, error)[0]
 
 
 def photo_blend(model, Z, recon_uint8, error):

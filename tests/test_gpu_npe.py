@@ -84,3 +84,61 @@ def test_sample_at_uint8(arch, n):
     got = m.sample_at_uint8(z)
     assert got.dtype == np.uint8 and got.shape == (n, 3, 64, 64) and np.array_equal(got, want)
     m.close()
+
+
+def _rgb_image():
+    rgb = np.zeros((3, 64, 64), np.uint8)
+    rgb[0] = 230; rgb[1] = 40; rgb[2] = 90
+    return rgb
+
+
+@pytest.mark.parametrize("graph", [1, 0])
+def test_brush_step_equals_the_composed_calls(model, graph):
+    """ian_brush_step (gradient + latent update + decoder in one submission) vs imgradRGB -> numpy update -> sample_at:
+    the latent is bit-identical (same float32 operations in NPE.py:205-209's order), so is the image (same kernels on the
+    same latent); 12 consecutive events so that the graph is captured and replayed, with the brush size changing."""
+    from neural_photo_editor_amd import npe_ops as N
+    model.handle.set_option("edit_graph", graph)
+    try:
+        IM, Z, RECON, ERROR = session(model, 11)
+        rgb8 = _rgb_image()
+        rgb = np.float32(N.to_tanh(np.float32(rgb8)))[None]
+        z_a = np.float32(Z).copy()
+        z_b = z_a.copy()
+        for i in range(12):
+            box = (20 + i, 22, 24 + i + (i % 3), 26 + (i % 3))
+            g = model.imgradRGB(box[0], box[1], box[2], box[3], rgb, z_a)
+            z_a = np.float32(z_a - np.float32(0.05) * (g * np.float32(1 + (box[2] - box[0]))))
+            x_a = model.sample_at(z_a)
+            z_b, x_b = model.brush_step(box[0], box[1], box[2], box[3], z_b, RGB=rgb, weight=0.05)
+            assert z_b.dtype == np.float32 and np.array_equal(z_b, z_a), i
+            assert np.array_equal(x_b, x_a), i
+        assert np.abs(z_a - np.float32(Z)).max() > 1e-4          # the brush moved the latent
+        # NPE.scroll: lighten / darken
+        for sign in (1.0, -1.0):
+            g = model.imgrad(10, 12, 16, 18, z_a)
+            z_a = np.float32(z_a + np.float32(sign * 0.1) * (g * np.float32(7)))
+            z_b, x_b = model.brush_step(10, 12, 16, 18, z_b, weight=0.1, sign=sign)
+            assert np.array_equal(z_b, z_a) and np.array_equal(x_b, model.sample_at(z_a))
+    finally:
+        model.handle.set_option("edit_graph", 1)
+
+
+def test_paint_event_photo_mode(model):
+    """NPE.paint in photo mode as one submission: (Z_new, IM) == brush_step + photo_blend_host on the decoded image."""
+    from neural_photo_editor_amd import npe_ops as N
+    IM, Z, RECON, ERROR = session(model, 13)
+    rgb8 = _rgb_image()
+    Zg = np.float32(Z).reshape(10, 10)
+    Zh = Zg.copy()
+    for i in range(6):
+        box = (30, 28 + i, 34, 32 + i)
+        Zh = N.brush_step(model, Zh, box, rgb8)                              # composed: imgradRGB + numpy
+        want_im, _ = N.photo_blend_host(model.sample_at(Zh.reshape(1, -1))[0], RECON, ERROR)
+        Zg, im = N.paint_event(model, Zg, box, rgb8, RECON, ERROR)
+        assert Zg.shape == (10, 10) and np.array_equal(Zg, Zh), i
+        assert im.dtype == np.uint8 and np.array_equal(im, want_im), i
+    # sample mode: the float image
+    Zs, x = N.paint_event(model, Zg, (5, 5, 9, 9), rgb8)
+    Zh = N.brush_step(model, Zh, (5, 5, 9, 9), rgb8)
+    assert np.array_equal(Zs, Zh) and np.array_equal(x, model.sample_at(Zh.reshape(1, -1))[0])
