@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""rocprofv3 kernel trace of scripts/train_profile.py -> profiles/<name>.md: per-kernel totals of the steady-state steps
+(everything after the marker launch: autotune candidates, layer construction and warm-up are cut away).
+
+usage: python scripts/summarize_train_profile.py gpurun_out/<tag>/trace/trace_kernel_trace.csv profiles/<name> [bench.json]"""
+import collections, csv, json, sys
+
+src, out = sys.argv[1], sys.argv[2]
+rows = list(csv.DictReader(open(src)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+mark = max(i for i, r in enumerate(rows) if "arange" in r["Kernel_Name"].lower())
+rows = rows[mark + 1:]
+tot = collections.OrderedDict()
+for r in rows:
+    n = r["Kernel_Name"].replace("void ian::", "").replace("ian::", "")
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    a = tot.setdefault(n, [0, 0.0])
+    a[0] += 1
+    a[1] += d
+total = sum(v[1] for v in tot.values())
+span = (int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / 1e6
+iters = sum(1 for r in rows if "adam_kernel" in r["Kernel_Name"]) // 4 or 1   # 4 parameter groups... per update: see below
+gemm = sum(v[1] for k, v in tot.items() if k.startswith("tapgemm_kernel") or k.startswith("tapwgrad_kernel"))
+train = None
+if len(sys.argv) > 3:
+    train = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1]).get("train_step")
+with open(out + ".md", "w") as f:
+    f.write("# rocprofv3 summary: %s\n\n" % out.split("/")[-1])
+    f.write("Command: `B=128 ITERS=4 rocprofv3 --kernel-trace --stats -- python scripts/train_profile.py` -- 4 updates of the full-IAN\n"
+            "training step (update_gen, update_discrim, update_gen, update_discrim; train_IAN.py:309-329) at 128 images per GPU, 1 GPU,\n"
+            "synthetic data, after the layer autotune and two warm-up updates (cut at the marker launch by\n"
+            "scripts/summarize_train_profile.py).\n\n")
+    f.write("Sum of kernel durations: **%.1f ms** for 4 updates (%.1f ms per update; first-to-last-kernel span %.1f ms).\n" % (total / 1e3, total / 4e3, span))
+    if train:
+        f.write("bench.py `train_step` of the same commit: update_gen %.1f ms, update_discrim %.1f ms wall, %.0f images/s.\n"
+                % (train["update_gen_ms"], train["update_discrim_ms"], train["images_per_s"]))
+    f.write("\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+    for k, v in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+        if v[1] / total < 0.0005:
+            continue
+        f.write("| %s | %d | %.2f | %.1f | %.2f |\n" % (k[:100], v[0], v[1] / 1e3, v[1] / v[0], 100 * v[1] / total))
+    f.write("\ntapgemm + tapwgrad (fp32 MFMA GEMMs): %.1f %% of kernel time.\n" % (100 * gemm / total))
+print(open(out + ".md").read()[:6000])
