@@ -102,6 +102,8 @@ hipError_t launch_conv1_nchw(const float* x, const float* w, const float* scale,
 // w packed [25 (ky,kx)][Cout4=4][Cin].
 hipError_t launch_deconv_out_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
                                   int n, int H, int W, int Cin, int Cout, int act, hipStream_t s);
+hipError_t launch_deconv_out_px(const float* x, const float* w, const float* scale, const float* shift, float* y, int n, int H,
+                                int W, int Cin, int Cout, int act, hipStream_t s);
 
 // y = act(x*scale[c]+shift[c]) on NHWC tensors (pixel stride = stride)
 hipError_t launch_affine(const float* x, float* y, const float* scale, const float* shift, long long npix, int C,

@@ -113,6 +113,7 @@ struct Options {
   int mdc_head = 2;                  // few-filter MDCL layers: 0 = tapgemm, 1 = VALU head kernel, 2 = + sibling layers fused
   int tg_variant = 2;                // K-loop schedule of tapgemm_kernel (kernels_tapgemm.hip); autotune picks per layer
   int tg_reduce_kp = 4;              // split-K reduce: lanes sharing one output element's slabs when a tile has >= 8 slabs
+  int dec_out_px = 1;                // ... and, below that batch, 8 lanes per output pixel instead of 16 tile workgroups
   int dec_out_mfma = 1;              // image-producing deconv (IAN_simple dec_out) on the matrix cores for batches >= 4
   int edit_graph = 1;                // batch-1 host-pointer calls (the NPE edit loop) replay captured hipGraphs
   int head_fused = 1;                // RGB-Beta head as head6 + head_tail (kernels_head.hip) when the graph matches IAN.py:183-207
@@ -217,6 +218,7 @@ bool apply_option(Options& o, const std::string& k, int value) {
   else if (k == "head_fused_min_n") o.head_fused_min_n = std::max(1, value);
   else if (k == "edit_graph") o.edit_graph = value;
   else if (k == "dec_out_mfma") o.dec_out_mfma = value;
+  else if (k == "dec_out_px") o.dec_out_px = value;
   else return false;
   return true;
 }
@@ -1111,6 +1113,11 @@ int run_op_fwd(ian_handle* h, OpPlan& op, int n, hipStream_t st) {
         while (n * bands < 256 && bands < 8 && (op.d.in_h % (4 * bands)) == 0) bands *= 2;   // 2 halo row pairs per band
         a.bands = bands;
         HIPCHK(h, launch_deconv_small(a, n, op.d.cout, st));
+        return 0;
+      }
+      if (op.edge && h->opt.dec_out_px && n < 4 && (src.cs == 64 || src.cs == 128 || src.cs == 256)) {
+        HIPCHK(h, launch_deconv_out_px(src.d, op.d_edge_w, op.d_scale, op.d_shift, dst.d, n, op.d.in_h, op.d.in_w, src.cs,
+                                       op.d.cout, op.d.act, st));
         return 0;
       }
       if (op.edge) {
@@ -2279,6 +2286,7 @@ int ian_set_option(ian_handle* h, const char* key, int32_t value) {
     free_schedules(op.bwd);
   }
   ++h->alloc_epoch;
+  h->dec_cache_valid = false;   // the resident activations were produced under the previous options
   return 0;
 }
 

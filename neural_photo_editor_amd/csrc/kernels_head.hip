@@ -319,36 +319,42 @@ hipError_t launch_head6_scatter(const float* comp, float* y0, float* y1, float* 
 __global__ __launch_bounds__(256) void head6_zbuild_kernel(const float* __restrict__ dy0, const float* __restrict__ dy1,
                                                            const float* __restrict__ dy2, int dys, float* __restrict__ Z, int zs,
                                                            int H, int W, int ntaps, const int* __restrict__ taps, long long npix) {
-  // one thread per (pixel, 4 columns): columns j = t*6 + 2k + f
-  const int c4n = zs >> 2;
-  const long long total = npix * c4n;
+  // one thread per (pixel, tap slot): three float2 gathers from the shifted pixel, six consecutive floats out; the slots
+  // past the last tap write the zero padding columns (zs - 6*ntaps <= 6 * extra slots)
+  const int slots = (zs + 5) / 6;
+  const long long total = npix * slots;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long q = i / c4n;
-    const int j0 = (int)(i % c4n) * 4;
-    const int qx = (int)(q % W), qy = (int)((q / W) % H);
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int j = j0 + e;
-      float r = 0.f;
-      if (j < ntaps * 6) {
-        const int t = j / 6, c6 = j % 6, kk = c6 >> 1, f = c6 & 1;
-        const int tp = taps[t];                       // (dy + 64) | (dx + 64) << 8
-        const int py = qy - ((tp & 0xFF) - 64), px = qx - ((tp >> 8) - 64);
-        if ((unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
-          const float* src = kk == 0 ? dy0 : (kk == 1 ? dy1 : dy2);
-          r = src[(q + (long long)(py - qy) * W + (px - qx)) * dys + f];
-        }
+    const long long q = i / slots;
+    const int t = (int)(i - q * slots);
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (t < ntaps) {
+      const int qx = (int)(q % W), qy = (int)((q / W) % H);
+      const int tp = taps[t];                       // (dy + 64) | (dx + 64) << 8
+      const int sy = (tp & 0xFF) - 64, sx = (tp >> 8) - 64;
+      const int py = qy - sy, px = qx - sx;
+      if ((unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
+        const long long src = (q - (long long)sy * W - sx) * dys;
+        const float2 a = *reinterpret_cast<const float2*>(dy0 + src);
+        const float2 b = *reinterpret_cast<const float2*>(dy1 + src);
+        const float2 c = *reinterpret_cast<const float2*>(dy2 + src);
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
       }
-      v[e] = r;
     }
-    *reinterpret_cast<float4*>(Z + q * zs + j0) = make_float4(v[0], v[1], v[2], v[3]);
+    float* dst = Z + q * zs + t * 6;
+    const int room = zs - t * 6;                    // >= 1
+    if (room >= 6) {
+      *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+      *reinterpret_cast<float2*>(dst + 2) = make_float2(v[2], v[3]);
+      *reinterpret_cast<float2*>(dst + 4) = make_float2(v[4], v[5]);
+    } else {
+      for (int e = 0; e < room; ++e) dst[e] = v[e];
+    }
   }
 }
 hipError_t launch_head6_zbuild(const float* dy0, const float* dy1, const float* dy2, int dys, float* Z, int zs, int H, int W,
                                int ntaps, const int* taps, long long npix, hipStream_t s) {
-  if (zs & 3) return hipErrorInvalidValue;
-  long long total = npix * (zs >> 2);
+  if ((zs & 1) || (dys & 1) || zs < 6 * ntaps) return hipErrorInvalidValue;
+  const long long total = npix * ((zs + 5) / 6);
   int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 64);
   hipLaunchKernelGGL(head6_zbuild_kernel, dim3(blocks), dim3(256), 0, s, dy0, dy1, dy2, dys, Z, zs, H, W, ntaps, taps, npix);
   return hipGetLastError();

@@ -303,6 +303,89 @@ static hipError_t launch_deconv_out_cin(const float* x, const float* w, const fl
   return hipGetLastError();
 }
 
+// The same layer for one or a few images (the interactive decoder, batch 1): 16 tile workgroups cannot fill 256 CUs and
+// their 1200-FMA lanes are a long serial chain, so here the work is cut the other way: 8 lanes per OUTPUT pixel, each lane
+// a strided eighth of the input channels (lane p: channels 4p + 32j -> the 8 lanes of a pixel read 128 contiguous bytes
+// per j), at most 9 taps of the pixel's parity class, operands straight from L2 (the whole input is 512 KB), an 8-lane
+// butterfly at the end.  No LDS, no barrier; 128 workgroups at batch 1.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void deconv_out_px_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            float* __restrict__ y, int n, int H, int W, int act) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int part = gid & 7;
+  const int opix = gid >> 3;
+  const int OH = 2 * H, OW = 2 * W;
+  if (opix >= n * OH * OW) return;            // whole 8-lane groups leave together
+  const int ox = opix % OW, oy = (opix / OW) % OH, b = opix / (OW * OH);
+  float acc[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+  // oy = 2*iy - 2 + ky  =>  ky = (oy & 1) + 2j, iy = (oy + 2 - ky) / 2
+#pragma unroll
+  for (int jy = 0; jy < 3; ++jy) {
+    const int ky = (oy & 1) + 2 * jy;
+    const int iy = (oy + 2 - ky) >> 1;
+    if (ky > 4 || (unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+    for (int jx = 0; jx < 3; ++jx) {
+      const int kx = (ox & 1) + 2 * jx;
+      const int ix = (ox + 2 - kx) >> 1;
+      if (kx > 4 || (unsigned)ix >= (unsigned)W) continue;
+      const float* xp = x + ((size_t)(b * H + iy) * W + ix) * CIN + part * 4;
+      const float* wp = w + (size_t)(ky * 5 + kx) * 4 * CIN + part * 4;
+#pragma unroll
+      for (int j = 0; j < CIN / 32; ++j) {
+        const float4 xv = *reinterpret_cast<const float4*>(xp + 32 * j);
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+          const float4 wv = *reinterpret_cast<const float4*>(wp + co * CIN + 32 * j);
+          float a = acc[co];
+          a = fmaf(xv.x, wv.x, a);
+          a = fmaf(xv.y, wv.y, a);
+          a = fmaf(xv.z, wv.z, a);
+          a = fmaf(xv.w, wv.w, a);
+          acc[co] = a;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) {
+    float v = acc[co];
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    if (part == 0) {
+      const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+      y[((size_t)(b * COUT + co) * OH + oy) * OW + ox] = m_act(v * sc + sh, act);
+    }
+  }
+}
+
+template <int CIN>
+static hipError_t launch_deconv_out_px_cin(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                                           int n, int H, int W, int Cout, int act, hipStream_t s) {
+  const long long threads = (long long)n * 4 * H * W * 8;
+  const dim3 grid((unsigned)((threads + 255) / 256));
+  switch (Cout) {
+    case 1: hipLaunchKernelGGL((deconv_out_px_kernel<CIN, 1>), grid, dim3(256), 0, s, x, w, scale, shift, y, n, H, W, act); break;
+    case 2: hipLaunchKernelGGL((deconv_out_px_kernel<CIN, 2>), grid, dim3(256), 0, s, x, w, scale, shift, y, n, H, W, act); break;
+    case 3: hipLaunchKernelGGL((deconv_out_px_kernel<CIN, 3>), grid, dim3(256), 0, s, x, w, scale, shift, y, n, H, W, act); break;
+    case 4: hipLaunchKernelGGL((deconv_out_px_kernel<CIN, 4>), grid, dim3(256), 0, s, x, w, scale, shift, y, n, H, W, act); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_deconv_out_px(const float* x, const float* w, const float* scale, const float* shift, float* y, int n, int H,
+                                int W, int Cin, int Cout, int act, hipStream_t s) {
+  if (Cout > 4 || Cout < 1) return hipErrorInvalidValue;
+  if (Cin == 128) return launch_deconv_out_px_cin<128>(x, w, scale, shift, y, n, H, W, Cout, act, s);
+  if (Cin == 64) return launch_deconv_out_px_cin<64>(x, w, scale, shift, y, n, H, W, Cout, act, s);
+  if (Cin == 256) return launch_deconv_out_px_cin<256>(x, w, scale, shift, y, n, H, W, Cout, act, s);
+  return hipErrorInvalidValue;
+}
+
 hipError_t launch_deconv_out_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
                                   int n, int H, int W, int Cin, int Cout, int act, hipStream_t s) {
   if (Cout > 4 || Cout < 1 || (H & 7) || (W & 7)) return hipErrorInvalidValue;

@@ -268,3 +268,20 @@ def test_sample_cli_writes_the_grid(tmp_path):
     assert data.startswith(b"P6\n576 384\n255\n") and len(data) == len(b"P6\n576 384\n255\n") + 384 * 576 * 3
     imgs = np.load(str(tmp_path / "g.npy"))
     assert imgs.shape == (54, 3, 64, 64) and imgs.dtype == np.uint8 and imgs.std() > 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_small_batch_image_layer_both_kernels(n):
+    """IAN_simple's dec_out (IAN_simple.py:171-181) below batch 4: the 8-lanes-per-output-pixel kernel (default) and the
+    tile kernel it replaced (dec_out_px=0) against the oracle and against each other."""
+    m, orc, P = model_for("IAN_simple")
+    z = O.make_latents(n, seed=40 + n)
+    want = orc.sample_at(z)
+    try:
+        got_px = m.sample_at(z)
+        m.handle.set_option("dec_out_px", 0)
+        got_tile = m.sample_at(z)
+    finally:
+        m.handle.set_option("dec_out_px", 1)
+    assert rel(got_px, want) < TOL and rel(got_tile, want) < TOL
+    assert rel(got_px, got_tile) < 1e-5
