@@ -113,6 +113,7 @@ struct Options {
   int mdc_head = 2;                  // few-filter MDCL layers: 0 = tapgemm, 1 = VALU head kernel, 2 = + sibling layers fused
   int tg_variant = 2;                // K-loop schedule of tapgemm_kernel (kernels_tapgemm.hip); autotune picks per layer
   int tg_reduce_kp = 4;              // split-K reduce: lanes sharing one output element's slabs when a tile has >= 8 slabs
+  int dense_gemv = 1;                // batch-1 backward of the dense layer fed by the latent as one GEMV launch
   int dec_out_px = 1;                // ... and, below that batch, 8 lanes per output pixel instead of 16 tile workgroups
   int dec_out_mfma = 1;              // image-producing deconv (IAN_simple dec_out) on the matrix cores for batches >= 4
   int edit_graph = 1;                // batch-1 host-pointer calls (the NPE edit loop) replay captured hipGraphs
@@ -219,6 +220,7 @@ bool apply_option(Options& o, const std::string& k, int value) {
   else if (k == "edit_graph") o.edit_graph = value;
   else if (k == "dec_out_mfma") o.dec_out_mfma = value;
   else if (k == "dec_out_px") o.dec_out_px = value;
+  else if (k == "dense_gemv") o.dense_gemv = value;
   else return false;
   return true;
 }
@@ -1501,7 +1503,11 @@ int run_decoder_backward(ian_handle* h, int mode, int c1, int r1, int c2, int r2
         e.res = touched[op.d.src] ? in.g : nullptr;
         e.mode = TG_EPI_BWD;
         const int ystride = (kind == IAN_OP_DENSE) ? (int)in.per_image() : in.cs;
-        if ((rc = run_tapgemm(h, op.bwd, 1, o.g, in.g, ystride, e, st))) return rc;
+        if (kind == IAN_OP_DENSE && h->opt.dense_gemv && !pe.scale && !pe.yfwd && pe.act == IAN_ACT_NONE && op.d.flat_c <= 0 &&
+            (op.bwd.Cin & 3) == 0 && op.bwd.Cout <= ystride) {
+          // the latent's own layer: slab [in][out], row j contiguous in the (permuted) output index = o.g's order
+          HIPCHK(h, launch_dense_bwd_gemv(o.g, op.bwd.d_w, op.bwd.Cout, op.bwd.Cin, e.res, in.g, st));
+        } else if ((rc = run_tapgemm(h, op.bwd, 1, o.g, in.g, ystride, e, st))) return rc;
         touched[op.d.src] = 1;
         if (kind == IAN_OP_MDC3 && op.d.src2 >= 0)  // residual operand of the fused ElemwiseSum: identity edge
           if ((rc = pass_to(o.g, o.cs, 0, op.d.src2, o.c))) return rc;

@@ -484,6 +484,39 @@ hipError_t launch_deconv_out_bwd(const float* g, const float* w, float* dx, cons
   return hipGetLastError();
 }
 
+// Batch-1 backward-data of the dense layer that consumes the latent (l_dec_fc2, IAN_simple.py:112-121; the last step of
+// API.py:59,64's T.grad): dz[j] = sum_k g[k] * Wb[j][k].  One workgroup per latent row j streams its 32 KB weight row with
+// every load in flight at once -- one launch instead of a split-K tap GEMM, its reduce pass and a row copy.
+__global__ __launch_bounds__(256) void dense_bwd_gemv_kernel(const float* __restrict__ g, const float* __restrict__ wb, int K,
+                                                             const float* __restrict__ res, float* __restrict__ dz) {
+  __shared__ float part[4];
+  const int row = blockIdx.x;
+  const float* wr = wb + (size_t)row * K;
+  float acc = 0.f;
+#pragma unroll 8
+  for (int k = threadIdx.x * 4; k < K; k += 1024) {
+    const float4 a = *reinterpret_cast<const float4*>(g + k);
+    const float4 w = *reinterpret_cast<const float4*>(wr + k);
+    acc = fmaf(a.x, w.x, acc);
+    acc = fmaf(a.y, w.y, acc);
+    acc = fmaf(a.z, w.z, acc);
+    acc = fmaf(a.w, w.w, acc);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = (part[0] + part[1]) + (part[2] + part[3]);
+    dz[row] = res ? v + res[row] : v;
+  }
+}
+hipError_t launch_dense_bwd_gemv(const float* g, const float* wb, int rows, int K, const float* res, float* dz, hipStream_t s) {
+  if (K & 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dense_bwd_gemv_kernel, dim3(rows), dim3(256), 0, s, g, wb, K, res, dz);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // elementwise helpers
 // ------------------------------------------------------------------------------------------------

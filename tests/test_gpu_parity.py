@@ -285,3 +285,21 @@ def test_small_batch_image_layer_both_kernels(n):
         m.handle.set_option("dec_out_px", 1)
     assert rel(got_px, want) < TOL and rel(got_tile, want) < TOL
     assert rel(got_px, got_tile) < 1e-5
+
+
+@pytest.mark.parametrize("arch", O.ARCHS)
+def test_latent_layer_backward_both_kernels(arch):
+    """The last step of the brush gradient (backward-data of l_dec_fc2 into the latent): the batch-1 GEMV launch (default) and
+    the split-K tap GEMM it replaced (dense_gemv=0) give the same gradient, and both match the golden one."""
+    m, orc, P = model_for(arch)
+    z = O.make_latents(1, seed=77)
+    try:
+        g1 = m.imgradRGB(8, 12, 40, 44, red_rgb(), z)
+        l1 = m.imgrad(8, 12, 40, 44, z)
+        m.handle.set_option("dense_gemv", 0)
+        g0 = m.imgradRGB(8, 12, 40, 44, red_rgb(), z)
+        l0 = m.imgrad(8, 12, 40, 44, z)
+    finally:
+        m.handle.set_option("dense_gemv", 1)
+    assert rel(g1, g0) < 1e-5 and rel(l1, l0) < 1e-5
+    assert np.abs(g1).max() > 0 and np.abs(l1).max() > 0
