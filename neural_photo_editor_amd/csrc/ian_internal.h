@@ -102,6 +102,8 @@ hipError_t launch_conv1_nchw(const float* x, const float* w, const float* scale,
 // w packed [25 (ky,kx)][Cout4=4][Cin].
 hipError_t launch_deconv_out_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
                                   int n, int H, int W, int Cin, int Cout, int act, hipStream_t s);
+hipError_t launch_dense_fwd_gemv(const float* x, const float* w, int K, int nout, const float* scale, const float* shift, int act,
+                                 float* y, hipStream_t s);
 hipError_t launch_dense_bwd_gemv(const float* g, const float* wb, int rows, int K, const float* res, float* dz, hipStream_t s);
 hipError_t launch_deconv_out_px(const float* x, const float* w, const float* scale, const float* shift, float* y, int n, int H,
                                 int W, int Cin, int Cout, int act, hipStream_t s);

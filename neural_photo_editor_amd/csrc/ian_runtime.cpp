@@ -1140,6 +1140,11 @@ int run_op_fwd(ian_handle* h, OpPlan& op, int n, hipStream_t st) {
       }
       return run_tapgemm(h, op.fwd, n, src.d, dst.d, dst.cs, fwd_epi(op, res), st);
     case IAN_OP_DENSE:
+      if (n == 1 && h->opt.dense_gemv && op.d.flat_c <= 0 && op.fwd.Cin <= 256 && (op.fwd.Cin & 31) == 0 && op.fwd.Cout >= 1024) {
+        // the latent's own layer at batch 1 (interactive decoder): one short-vector GEMV launch, no split-K pass
+        HIPCHK(h, launch_dense_fwd_gemv(src.d, op.fwd.d_w, op.fwd.Cin, op.fwd.Cout, op.d_scale, op.d_shift, op.d.act, dst.d, st));
+        return 0;
+      }
       return run_tapgemm(h, op.fwd, n, src.d, dst.d, (int)dst.per_image(), fwd_epi(op, nullptr), st);
     case IAN_OP_AFFINE:
       HIPCHK(h, launch_affine(src.d, dst.d, op.d_scale, op.d_shift, (long long)n * src.h * src.w, src.c, src.cs,
@@ -1212,7 +1217,8 @@ std::vector<TgChoice> tune_candidates(const TgLayer& L, int nimg) {
         if (slabs * sh.bm * sh.bn * 4 > (512ll << 20)) continue;  // slab workspace cap
         if (slabs > 16384) continue;
       }
-      for (int var : {1, 2}) {   // 3 (LDS-DMA staging) measured 5 % slower on every 5x5 layer: selectable, not a candidate
+      for (int var : {1, 2, 4}) {   // 3 (LDS-DMA staging) measured 5 % slower on every 5x5 layer: selectable, not a candidate
+        if (var == 4 && (M > 1024 || cfg == TG_256x128)) continue;   // the three-deep load queue is for latency-bound items (few images)
         TgChoice c;
         c.cfg = cfg;
         c.max_steps = ms;

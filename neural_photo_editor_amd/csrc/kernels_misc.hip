@@ -511,6 +511,38 @@ __global__ __launch_bounds__(256) void dense_bwd_gemv_kernel(const float* __rest
     dz[row] = res ? v + res[row] : v;
   }
 }
+// Batch-1 forward of a dense layer fed by a short vector (l_dec_fc2: 100 -> 8192): y[o] = act(scale[o] * sum_k x[k] W[o][k]
+// + shift[o]), slab [out][K] (K = padded input width, zero beyond the real inputs).  8 lanes per output, lane p takes the
+// input columns 4p + 32j so that the 8 lanes of an output read whole 128-byte lines; an 8-lane butterfly at the end.
+__global__ __launch_bounds__(256) void dense_fwd_gemv_kernel(const float* __restrict__ x, const float* __restrict__ w, int K,
+                                                             int nout, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int act, float* __restrict__ y) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int part = gid & 7, o = gid >> 3;
+  if (o >= nout) return;                      // whole 8-lane groups leave together
+  const float* wr = w + (size_t)o * K + part * 4;
+  const float* xr = x + part * 4;
+  float acc = 0.f;
+  for (int k = 0; k < K; k += 32) {
+    const float4 a = *reinterpret_cast<const float4*>(xr + k);
+    const float4 b = *reinterpret_cast<const float4*>(wr + k);
+    acc = fmaf(a.x, b.x, acc);
+    acc = fmaf(a.y, b.y, acc);
+    acc = fmaf(a.z, b.z, acc);
+    acc = fmaf(a.w, b.w, acc);
+  }
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  acc += __shfl_xor(acc, 4);
+  if (part == 0) y[o] = m_act(acc * (scale ? scale[o] : 1.f) + (shift ? shift[o] : 0.f), act);
+}
+hipError_t launch_dense_fwd_gemv(const float* x, const float* w, int K, int nout, const float* scale, const float* shift, int act,
+                                 float* y, hipStream_t s) {
+  if (K & 31) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dense_fwd_gemv_kernel, dim3((nout * 8 + 255) / 256), dim3(256), 0, s, x, w, K, nout, scale, shift, act, y);
+  return hipGetLastError();
+}
+
 hipError_t launch_dense_bwd_gemv(const float* g, const float* wb, int rows, int K, const float* res, float* dz, hipStream_t s) {
   if (K & 3) return hipErrorInvalidValue;
   hipLaunchKernelGGL(dense_bwd_gemv_kernel, dim3(rows), dim3(256), 0, s, g, wb, K, res, dz);

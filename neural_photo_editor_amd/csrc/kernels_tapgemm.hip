@@ -195,6 +195,7 @@ __device__ __forceinline__ void tg_store(const TgParams& p, const TgItem& it, co
 //   1: loads -> kk 0,1 -> LDS stores -> kk 2,3 -> barrier         (stores hidden under the second half's MFMAs)
 //   3: as 2, but the tiles travel global -> LDS by LDS-DMA into an XOR-swizzled unpadded image (no staging registers,
 //      no ds_write)
+//   4: the loads of three K-steps in flight (register queue): for items of few K-steps with little MFMA work each (batch 1)
 //   2: rotated: the fragments of the last k group are read before the barrier and their MFMAs issued after it,
 //      covering the barrier, the next tile's global-load issue and the first fragment reads of the new buffer
 template <int BM, int BN, int WM, int WN, int VAR>
@@ -257,29 +258,31 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-#define TG_LOAD_TILE()                                                                                   \
+#define TG_LOAD_INTO(RA, RB)                                                                                 \
   {                                                                                                      \
     const TgTap tp = p.taps[cl.tap0 + tap];                                                              \
     const unsigned doff = (unsigned)(((tp.dy * p.IW + tp.dx) * p.Cin + (cstep << 5)) * 4);               \
     _Pragma("unroll") for (int j = 0; j < A_CH; ++j) {                                                   \
       const int iy = a_iy0[j] + tp.dy, ix = a_ix0[j] + tp.dx;                                            \
       const bool ok = ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);                 \
-      ra[j] = buf_load4(xrsrc, ok ? a_off[j] + doff : 0xFFFFFFF0u, 0);                                   \
+      RA[j] = buf_load4(xrsrc, ok ? a_off[j] + doff : 0xFFFFFFF0u, 0);                                   \
     }                                                                                                    \
     const unsigned wsoff = w_cls + (unsigned)tap * slab_bytes + (unsigned)(cstep << 7);                         \
-    _Pragma("unroll") for (int j = 0; j < B_CH; ++j) rb[j] = buf_load4(wrsrc, w_row + j * w_rstep, wsoff); \
+    _Pragma("unroll") for (int j = 0; j < B_CH; ++j) RB[j] = buf_load4(wrsrc, w_row + j * w_rstep, wsoff); \
     if (++cstep == kpt) {                                                                                \
       cstep = 0;                                                                                         \
       ++tap;                                                                                             \
     }                                                                                                    \
   }
-#define TG_STORE_TILE(buf)                                                                               \
+#define TG_LOAD_TILE() TG_LOAD_INTO(ra, rb)
+#define TG_STORE_FROM(RA, RB, buf)                                                                              \
   {                                                                                                      \
     float* a_ = As + (buf) * BM * TG_LDS + r0 * TG_LDS + c4;                                             \
     float* b_ = Bs + (buf) * BN * TG_LDS + r0 * TG_LDS + c4;                                             \
-    _Pragma("unroll") for (int j = 0; j < A_CH; ++j) *reinterpret_cast<float4*>(a_ + 32 * j * TG_LDS) = ra[j]; \
-    _Pragma("unroll") for (int j = 0; j < B_CH; ++j) *reinterpret_cast<float4*>(b_ + 32 * j * TG_LDS) = rb[j]; \
+    _Pragma("unroll") for (int j = 0; j < A_CH; ++j) *reinterpret_cast<float4*>(a_ + 32 * j * TG_LDS) = RA[j]; \
+    _Pragma("unroll") for (int j = 0; j < B_CH; ++j) *reinterpret_cast<float4*>(b_ + 32 * j * TG_LDS) = RB[j]; \
   }
+#define TG_STORE_TILE(buf) TG_STORE_FROM(ra, rb, buf)
 
   const int arow = wm * (BM / WM) + (lane & 31);
   const int brow = wn * (BN / WN) + (lane & 31);
@@ -351,12 +354,43 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
       tg_frag_mfma<FM, FN>(aw, bw, acc);
     }
 #undef TG_DMA_TILE
-  } else {
+  } else if (VAR != 4) {
   TG_LOAD_TILE();
   TG_STORE_TILE(0);
   __syncthreads();
   }
   if (DMA) {
+  } else if (VAR == 4) {
+    // ---- VAR 4: register queue three tiles deep.  With few images an item is a handful of K-steps whose 16-64 MFMAs
+    // (0.4-1.7 us) cannot cover a 1-2 us weight fetch from the Infinity Cache: the one-step prefetch of the other schedules
+    // turns the K loop into a latency chain (8 steps x 1.5 us at batch 1).  Here the loads of K-steps s+1..s+3 are in
+    // flight while step s computes; the oldest one is written to the idle LDS buffer at the top of the step (its load was
+    // issued three steps ago) and its registers are reloaded at once.  Same MFMA order -> same bits.
+    float4 q0a[A_CH], q0b[B_CH], q1a[A_CH], q1b[B_CH], q2a[A_CH], q2b[B_CH];
+    int issued = 1;
+    TG_LOAD_TILE();
+    if (issued < nks) { TG_LOAD_INTO(q0a, q0b); ++issued; }
+    if (issued < nks) { TG_LOAD_INTO(q1a, q1b); ++issued; }
+    if (issued < nks) { TG_LOAD_INTO(q2a, q2b); ++issued; }
+    TG_STORE_TILE(0);
+    __syncthreads();
+    int s = 0;
+#define TG_QSTEP(QA, QB)                                                                   \
+    if (s >= nks - 1) break;                                                                 \
+    TG_STORE_FROM(QA, QB, cur ^ 1);                                                          \
+    if (issued < nks) { TG_LOAD_INTO(QA, QB); ++issued; }                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    tg_compute<FM, FN>(a_base + cur * BM * TG_LDS, b_base + cur * BN * TG_LDS, acc);         \
+    __syncthreads();                                                                         \
+    cur ^= 1;                                                                                \
+    ++s;
+    while (true) {
+      TG_QSTEP(q0a, q0b)
+      TG_QSTEP(q1a, q1b)
+      TG_QSTEP(q2a, q2b)
+    }
+#undef TG_QSTEP
+    tg_compute<FM, FN>(a_base + cur * BM * TG_LDS, b_base + cur * BN * TG_LDS, acc);
   } else if (VAR == 0) {
     for (int s = 0; s < nks - 1; ++s) {
       TG_LOAD_TILE();  // K-step s+1: in flight during the MFMAs below
@@ -433,6 +467,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
   }
 #undef TG_LOAD_TILE
 #undef TG_STORE_TILE
+#undef TG_LOAD_INTO
+#undef TG_STORE_FROM
 
   // ---- epilogue. C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
   if (it.slab >= 0) {
@@ -555,6 +591,7 @@ static hipError_t launch_cfg(const TgParams& p, int nitems, hipStream_t s) {
     case 1: return launch_var<BM, BN, WM, WN, 1>(p, nitems, s);
     case 2: return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);
     case 3: return launch_var<BM, BN, WM, WN, 3>(p, nitems, s);
+    case 4: return launch_var<BM, BN, WM, WN, 4>(p, nitems, s);
     case 10: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 10>(p, nitems, s); break;   // timing-only ablations
     case 11: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 11>(p, nitems, s); break;
     case 12: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 12>(p, nitems, s); break;

@@ -103,7 +103,7 @@ def test_every_tile_config_and_split_policy(cfg):
     ref = orc.reconstruct(x)
     try:
         outs = []
-        for var in (0, 1, 2, 3):       # K-loop schedules (3 = LDS-DMA staging): same arithmetic in the same order -> identical bits
+        for var in (0, 1, 2, 3, 4):    # K-loop schedules (3 = LDS-DMA staging, 4 = three-deep load queue): same arithmetic in the same order -> identical bits
             m.handle.set_option("tg_variant", var)
             m.handle.set_option("tg_cfg", cfg)
             m.handle.set_option("tg_split", 1)
@@ -303,3 +303,11 @@ def test_latent_layer_backward_both_kernels(arch):
         m.handle.set_option("dense_gemv", 1)
     assert rel(g1, g0) < 1e-5 and rel(l1, l0) < 1e-5
     assert np.abs(g1).max() > 0 and np.abs(l1).max() > 0
+    # forward of the same layer: GEMV launch vs tap GEMM
+    try:
+        x1 = m.sample_at(z)
+        m.handle.set_option("dense_gemv", 0)
+        x0 = m.sample_at(z)
+    finally:
+        m.handle.set_option("dense_gemv", 1)
+    assert rel(x1, x0) < 1e-5 and rel(x1, orc.sample_at(z)) < TOL
