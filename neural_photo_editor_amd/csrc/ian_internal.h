@@ -24,7 +24,8 @@ struct TgItem {  // one workgroup's job (host-built table, 32 B)
   int cls, m0, n0;
   int ks0, ks1;  // K-step range [ks0,ks1) of 32-channel steps over (tap, ci-chunk)
   int slab;      // split-K: slab tile index; -1 = direct epilogue
-  int pad0, pad1;
+  int tile;      // split-K: index of the output tile in the TgTile table (fused combine: counter + slab range)
+  int pad1;
 };
 struct TgTile {  // reduce pass: one output tile
   int cls, m0, n0, slab0, nsplit, pad0, pad1, pad2;
@@ -62,6 +63,8 @@ struct TgParams {
   int CoutPad;
   unsigned x_bytes, w_bytes;  // buffer-descriptor extents (out-of-range offsets read as zero)
   int variant;                // K-loop schedule (kernels_tapgemm.hip)
+  const TgTile* tiles;        // split-K with the combine fused into this launch (counters != nullptr): the tile table ...
+  int* counters;              // ... and one arrival counter per tile (zero between launches); nullptr = separate reduce pass
 };
 
 struct TgReduceParams {

@@ -44,6 +44,7 @@ struct Schedule {
   TgItem* d_items = nullptr;
   int ntiles = 0;  // >0 => split-K: slabs + reduce pass
   TgTile* d_tiles = nullptr;
+  int* d_counters = nullptr;   // split-K combine fused into the tapgemm launch: one arrival counter per tile (zero at rest)
   size_t slab_tiles = 0;
   int max_nsplit = 1;
   std::vector<TgItem> h_items;  // kept for tests / debugging
@@ -112,6 +113,7 @@ struct Options {
   int tg_nosplit_min_out = 1 << 30;  // outputs (M*Cout) above which 64x64 is forced even if it under-fills
   int mdc_head = 2;                  // few-filter MDCL layers: 0 = tapgemm, 1 = VALU head kernel, 2 = + sibling layers fused
   int tg_variant = 2;                // K-loop schedule of tapgemm_kernel (kernels_tapgemm.hip); autotune picks per layer
+  int tg_fused_reduce_max_m = 1024;  // split-K combine by the last-arriving workgroup (no reduce launch) when images*QH*QW <= this
   int tg_reduce_kp = 4;              // split-K reduce: lanes sharing one output element's slabs when a tile has >= 8 slabs
   int dense_gemv = 1;                // batch-1 backward of the dense layer fed by the latent as one GEMV launch
   int dec_out_px = 1;                // ... and, below that batch, 8 lanes per output pixel instead of 16 tile workgroups
@@ -180,6 +182,7 @@ struct ian_handle {
     hipGraphExec_t exec = nullptr;
     long long epoch = -1;
     int warm = 0;
+    long long warm_epoch = -1;   // the eager pass counts only for the options / schedules / buffers it ran with
   };
   long long alloc_epoch = 0;
   hipStream_t edit_stream = nullptr;
@@ -214,6 +217,7 @@ bool apply_option(Options& o, const std::string& k, int value) {
   else if (k == "tg_nosplit_min_out") o.tg_nosplit_min_out = value;
   else if (k == "tg_variant") o.tg_variant = value;
   else if (k == "tg_reduce_kp") o.tg_reduce_kp = value;
+  else if (k == "tg_fused_reduce_max_m") o.tg_fused_reduce_max_m = value;
   else if (k == "mdc_head") o.mdc_head = value;
   else if (k == "head_fused") o.head_fused = value;
   else if (k == "head_fused_min_n") o.head_fused_min_n = std::max(1, value);
@@ -727,11 +731,12 @@ void build_schedule(const ian_handle* h, const TgLayer& L, int nimg, Schedule& S
     ns = (ksteps + per - 1) / per;
     if (split) S.max_nsplit = std::max(S.max_nsplit, ns);
     // slab indices: tile-major so that the reduce pass reads contiguous slabs
-    std::vector<int> slab0((size_t)tiles_m * tiles_n, -1);
+    std::vector<int> slab0((size_t)tiles_m * tiles_n, -1), tile_id((size_t)tiles_m * tiles_n, -1);
     if (split) {
       for (int mt = 0; mt < tiles_m; ++mt)
         for (int nt = 0; nt < tiles_n; ++nt) {
           slab0[(size_t)mt * tiles_n + nt] = (int)slab_next;
+          tile_id[(size_t)mt * tiles_n + nt] = (int)S.h_tiles.size();
           TgTile t{c, mt * sh.bm, nt * sh.bn, (int)slab_next, ns, 0, 0, 0};
           S.h_tiles.push_back(t);
           slab_next += ns;
@@ -745,7 +750,8 @@ void build_schedule(const ian_handle* h, const TgLayer& L, int nimg, Schedule& S
           g.weight = k1 - k0;
           for (int nt = nb; nt < std::min(tiles_n, nb + gn); ++nt)
             for (int mt = mb; mt < std::min(tiles_m, mb + gm); ++mt) {
-              TgItem it{c, mt * sh.bm, nt * sh.bn, k0, k1, split ? slab0[(size_t)mt * tiles_n + nt] + s : -1, 0, 0};
+              TgItem it{c, mt * sh.bm, nt * sh.bn, k0, k1, split ? slab0[(size_t)mt * tiles_n + nt] + s : -1,
+                        tile_id[(size_t)mt * tiles_n + nt], 0};
               g.items.push_back(it);
             }
           groups.push_back(std::move(g));
@@ -784,6 +790,10 @@ int get_schedule(ian_handle* h, TgLayer& L, int nimg, Schedule** out) {
     int rc;
     if ((rc = upload(h, S.h_items, &S.d_items))) return rc;
     if ((rc = upload(h, S.h_tiles, &S.d_tiles))) return rc;
+    if (S.ntiles > 0) {
+      HIPCHK(h, hipMalloc((void**)&S.d_counters, S.ntiles * sizeof(int)));
+      HIPCHK(h, hipMemset(S.d_counters, 0, S.ntiles * sizeof(int)));
+    }
     const TgShape sh = tg_shape(S.cfg);
     const size_t need = S.slab_tiles * sh.bm * sh.bn;
     if (need > h->slab_cap) {
@@ -803,6 +813,7 @@ void free_schedule_for(TgLayer& L, int nimg) {
   if (it == L.sched.end()) return;
   if (it->second.d_items) (void)hipFree(it->second.d_items);
   if (it->second.d_tiles) (void)hipFree(it->second.d_tiles);
+  if (it->second.d_counters) (void)hipFree(it->second.d_counters);
   L.sched.erase(it);
 }
 
@@ -810,6 +821,7 @@ void free_schedules(TgLayer& L) {
   for (auto& kv : L.sched) {
     if (kv.second.d_items) (void)hipFree(kv.second.d_items);
     if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
+    if (kv.second.d_counters) (void)hipFree(kv.second.d_counters);
   }
   L.sched.clear();
 }
@@ -858,6 +870,9 @@ int run_tapgemm(ian_handle* h, TgLayer& L, int nimg, const float* x, float* y, i
   p.x_bytes = (unsigned)xb;
   p.w_bytes = (unsigned)(L.w_floats * sizeof(float));
   p.variant = S->variant >= 0 ? S->variant : h->opt.tg_variant;
+  const bool fused = S->ntiles > 0 && p.M <= h->opt.tg_fused_reduce_max_m;
+  p.tiles = S->d_tiles;
+  p.counters = fused ? S->d_counters : nullptr;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (h->prof) {
     if (h->ev_used == h->ev_pool.size()) {
@@ -870,7 +885,7 @@ int run_tapgemm(ian_handle* h, TgLayer& L, int nimg, const float* x, float* y, i
     HIPCHK(h, hipEventRecord(ev->first, st));
   }
   HIPCHK(h, launch_tapgemm(S->cfg, p, S->nitems, st));
-  if (S->ntiles > 0) {
+  if (S->ntiles > 0 && !fused) {
     TgReduceParams r;
     r.slab = h->d_slab; r.y = y; r.tiles = S->d_tiles; r.classes = L.d_classes; r.epi = epi;
     r.M = p.M; r.qw_shift = p.qw_shift; r.qhw_shift = p.qhw_shift; r.so = L.so; r.OH = L.OH; r.OW = L.OW;
@@ -1590,10 +1605,14 @@ int run_or_replay(ian_handle* h, ian_handle::EditGraph& G, F&& body) {
     G.exec = nullptr;
     G.warm = 0;
   }
-  if (G.warm < 1 || h->graph_failed) {
+  if (G.warm < 1 || G.warm_epoch != h->alloc_epoch || h->graph_failed) {
+    // a capture must replay exactly what an eager pass has already done once: first launches set function attributes,
+    // build and upload schedules, allocate -- none of which may happen inside a capture.  An option change or a
+    // (re)allocation between the eager pass and the capture (alloc_epoch moved) therefore asks for another eager pass.
     const long long e0 = h->alloc_epoch;
     const int rc = body();
-    G.warm = (h->alloc_epoch == e0) ? G.warm + 1 : 0;   // something was (re)allocated: run eagerly once more
+    G.warm = (h->alloc_epoch == e0) ? 1 : 0;
+    G.warm_epoch = h->alloc_epoch;
     return rc;
   }
   const long long e0 = h->alloc_epoch;
@@ -1608,6 +1627,13 @@ int run_or_replay(ian_handle* h, ian_handle::EditGraph& G, F&& body) {
   if (rc || e != hipSuccess || !g || h->alloc_epoch != e0) {   // never replay a graph whose capture hit an error or an allocation
     (void)hipGetLastError();
     if (g) (void)hipGraphDestroy(g);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {   // an invalidated capture may still hold the stream
+      hipGraph_t g2 = nullptr;
+      (void)hipStreamEndCapture(st, &g2);
+      if (g2) (void)hipGraphDestroy(g2);
+    }
+    (void)hipGetLastError();
     h->graph_failed = true;
     h->err.clear();
     return body();

@@ -485,7 +485,43 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
           const int col = wn * (BN / WN) + j * 32 + col_l;
           sl[row * BN + col] = acc[i][j][r];
         }
-    return;
+    if (!p.counters) return;   // a tapgemm_reduce launch follows
+    // ---- split-K combine by the workgroup that arrives last at the tile (no second launch: at batch 1 a launch
+    // boundary costs as much as the K loop).  Every partial is fenced to the device before the arrival counter is
+    // bumped; the last arriver re-reads ALL slabs of the tile, its own included, in slab order -> the sum does not
+    // depend on who arrives last.  The counter is back at zero when the launch ends.
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    const TgTile tl = p.tiles[it.tile];
+    if (tid == 0) {
+      const int ticket = atomicAdd(&p.counters[it.tile], 1);
+      s_last = (ticket == tl.nsplit - 1);
+      if (s_last) p.counters[it.tile] = 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float* s0 = p.slab + (size_t)tl.slab0 * (BM * BN);
+    for (int k = 0; k < tl.nsplit; ++k) {
+      const float* sk = s0 + (size_t)k * (BM * BN);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+            const int col = wn * (BN / WN) + j * 32 + col_l;
+            acc[i][j][r] += __builtin_nontemporal_load(sk + row * BN + col);
+          }
+    }
   }
   tg_store<BM, BN, WM, WN>(p, it, cl, acc, wm, wn, lane);
 }
