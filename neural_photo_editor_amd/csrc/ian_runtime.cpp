@@ -113,7 +113,9 @@ struct Options {
   int tg_nosplit_min_out = 1 << 30;  // outputs (M*Cout) above which 64x64 is forced even if it under-fills
   int mdc_head = 2;                  // few-filter MDCL layers: 0 = tapgemm, 1 = VALU head kernel, 2 = + sibling layers fused
   int tg_variant = 2;                // K-loop schedule of tapgemm_kernel (kernels_tapgemm.hip); autotune picks per layer
-  int tg_fused_reduce_max_m = 1024;  // split-K combine by the last-arriving workgroup (no reduce launch) when images*QH*QW <= this
+  int tg_fused_reduce_max_m = 0;     // split-K combine by the last-arriving workgroup (no reduce launch) when images*QH*QW <= this.
+                                     // OFF: measured 3x slower per layer at batch 1 (14 -> 37-48 us) -- the agent-scope release every
+                                     // workgroup needs before it bumps the arrival counter is a whole-L2 writeback on gfx950
   int tg_reduce_kp = 4;              // split-K reduce: lanes sharing one output element's slabs when a tile has >= 8 slabs
   int dense_gemv = 1;                // batch-1 backward of the dense layer fed by the latent as one GEMV launch
   int dec_out_px = 1;                // ... and, below that batch, 8 lanes per output pixel instead of 16 tile workgroups
