@@ -166,6 +166,7 @@ struct MdcThinArgs {
   const float* shift;
   float* y;        // NHWC, pixel stride ys
   int n, H, W, xs, ys, Cout, CoutPad, CinPad, ntaps, act;
+  int no_tile;     // 1: never take the LDS-staged form (A/B tests)
   signed char dy[48], dx[48];
 };
 hipError_t launch_mdc_thin(const MdcThinArgs& a, hipStream_t s);

@@ -117,6 +117,8 @@ struct Options {
                                      // OFF: measured 3x slower per layer at batch 1 (14 -> 37-48 us) -- the agent-scope release every
                                      // workgroup needs before it bumps the arrival counter is a whole-L2 writeback on gfx950
   int tg_reduce_kp = 4;              // split-K reduce: lanes sharing one output element's slabs when a tile has >= 8 slabs
+  int wg_target_items = 1024;        // tapwgrad: split the pixel range until taps x channel tiles x splits reaches this many workgroups
+  int mdc_thin_tile = 1;             // thin MDCL (G_b / B_b and their backward-data) with the input rows staged through LDS
   int dense_gemv = 1;                // batch-1 backward of the dense layer fed by the latent as one GEMV launch
   int dec_out_px = 1;                // ... and, below that batch, 8 lanes per output pixel instead of 16 tile workgroups
   int dec_out_mfma = 1;              // image-producing deconv (IAN_simple dec_out) on the matrix cores for batches >= 4
@@ -227,6 +229,8 @@ bool apply_option(Options& o, const std::string& k, int value) {
   else if (k == "dec_out_mfma") o.dec_out_mfma = value;
   else if (k == "dec_out_px") o.dec_out_px = value;
   else if (k == "dense_gemv") o.dense_gemv = value;
+  else if (k == "mdc_thin_tile") o.mdc_thin_tile = value;
+  else if (k == "wg_target_items") o.wg_target_items = value;
   else return false;
   return true;
 }
@@ -912,8 +916,9 @@ bool mdc_thin_eligible(const ian_handle* h, const TgLayer& L) {
   return true;
 }
 
-void mdc_thin_fill(MdcThinArgs& a, const TgLayer& L, const float* x, int xs, float* y, int ys, int n) {
+void mdc_thin_fill(MdcThinArgs& a, const TgLayer& L, const float* x, int xs, float* y, int ys, int n, const ian_handle* h) {
   memset(&a, 0, sizeof a);
+  a.no_tile = h->opt.mdc_thin_tile ? 0 : 1;
   a.x = x; a.w = L.d_w; a.y = y; a.n = n; a.H = L.IH; a.W = L.IW; a.xs = xs; a.ys = ys; a.Cout = L.Cout;
   a.CoutPad = L.CoutPad; a.CinPad = L.Cin; a.ntaps = (int)L.taps.size();
   for (int t = 0; t < a.ntaps; ++t) { a.dy[t] = (signed char)L.taps[t].dy; a.dx[t] = (signed char)L.taps[t].dx; }
@@ -1150,7 +1155,7 @@ int run_op_fwd(ian_handle* h, OpPlan& op, int n, hipStream_t st) {
       if (mdc_head_eligible(h, op)) return run_mdc_head_group(h, op, n, st);
       if (mdc_thin_eligible(h, op.fwd)) {
         MdcThinArgs a;
-        mdc_thin_fill(a, op.fwd, src.d, src.cs, dst.d, dst.cs, n);
+        mdc_thin_fill(a, op.fwd, src.d, src.cs, dst.d, dst.cs, n, h);
         a.res = res; a.scale = op.d_scale; a.shift = op.d_shift; a.act = op.d.act;
         HIPCHK(h, launch_mdc_thin(a, st));
         return 0;
@@ -2454,7 +2459,8 @@ int build_wg_schedule(ian_layer* l, int nimg, WgSchedule** out) {
   const int ntaps = (int)L.taps.size();
   const long long base = (long long)ntaps * tiles_co * tiles_ci;
   const int steps = (M + 31) / 32;
-  int nsplit = (int)std::max<long long>(1, (1024 + base - 1) / base);
+  const int target = std::max(1, l->ctx.opt.wg_target_items);
+  int nsplit = (int)std::max<long long>(1, (target + base - 1) / base);
   nsplit = std::min(nsplit, std::max(1, steps / 4));  // at least 4 K-steps (128 pixels) per item
   const int per = ((steps + nsplit - 1) / nsplit) * 32;
   nsplit = (M + per - 1) / per;
@@ -2642,7 +2648,7 @@ int ian_layer_forward(ian_layer* l, const float* x, int32_t n, float* y, int32_t
   }
   if (l->op.d.kind == IAN_OP_MDC3 && mdc_thin_eligible(&l->ctx, l->op.fwd)) {
     MdcThinArgs a;
-    mdc_thin_fill(a, l->op.fwd, x, l->op.fwd.Cin, y, y_stride, n);
+    mdc_thin_fill(a, l->op.fwd, x, l->op.fwd.Cin, y, y_stride, n, &l->ctx);
     a.res = res; a.shift = bias; a.act = act;
     LHIP(l, launch_mdc_thin(a, (hipStream_t)stream));
     return 0;
@@ -2660,7 +2666,7 @@ int ian_layer_backward_data(ian_layer* l, const float* dy, int32_t n, float* dx,
   if (dx_stride <= 0) dx_stride = round_up(l->op.bwd.Cout, 32);
   if (l->op.d.kind == IAN_OP_MDC3 && mdc_thin_eligible(&l->ctx, l->op.bwd)) {
     MdcThinArgs a;
-    mdc_thin_fill(a, l->op.bwd, dy, l->op.bwd.Cin, dx, dx_stride, n);
+    mdc_thin_fill(a, l->op.bwd, dy, l->op.bwd.Cin, dx, dx_stride, n, &l->ctx);
     a.res = accumulate ? dx : nullptr;
     LHIP(l, launch_mdc_thin(a, (hipStream_t)stream));
     return 0;

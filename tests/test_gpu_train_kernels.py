@@ -432,3 +432,37 @@ def test_head6_backward_equals_three_layer_calls(env, n, accumulate):
     assert rel(from_nhwc(dx_o, 128), xt.grad.numpy()) < TOL
     for l in layers:
         l.close()
+
+
+@pytest.mark.parametrize("cin", [2, 4])
+def test_thin_mdcl_lds_staged_equals_direct(env, cin, monkeypatch):
+    """G_b / B_b (IAN.py:187-206; 2 or 4 input channels, 2 filters): the LDS-staged kernel (enough row bands to fill the
+    chip) and the direct-from-L1 kernel run the same FMAs in the same order -> identical forward and backward-data."""
+    lib, T, k = env
+    n, sc = 32, [2, 3, 4]
+    rs = np.random.RandomState(70 + cin)
+    W = (rs.randn(2, cin, 3, 3) * 0.3).astype(np.float32)
+    coeffs = [rs.uniform(0.5, 1.5, 2).astype(np.float32) for _ in range(4)]
+    x = to_nhwc(rs.randn(n, cin, 64, 64).astype(np.float32))
+    dy = to_nhwc(rs.randn(n, 2, 64, 64).astype(np.float32))
+    outs = []
+    for tile in (1, 0):
+        monkeypatch.setenv("IAN_OPTS", "mdc_thin_tile=%d" % tile)
+        layer = T.Layer(lib, T.K_MDC, cin, 2, 64, 64, scales=sc)
+        params = [torch.from_numpy(a.ravel()).cuda() for a in [W] + coeffs]
+        layer.set_params(params)
+        y = torch.zeros(n, 64, 64, 32, device="cuda")
+        dx = torch.zeros(n, 64, 64, 32, device="cuda")
+        layer.forward(x, n, y, act=5)
+        layer.backward_data(dy, n, dx)
+        torch.cuda.synchronize()
+        outs.append((y.cpu().numpy(), dx.cpu().numpy()))
+        layer.close()
+    assert np.abs(outs[0][0]).max() > 0 and np.abs(outs[0][1]).max() > 0
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    xt = torch.tensor(from_nhwc(x, cin), dtype=torch.float64)
+    Wt = torch.tensor(W, dtype=torch.float64)
+    ref = F.conv2d(xt, Wt, padding=1) * torch.tensor(coeffs[0], dtype=torch.float64).reshape(1, -1, 1, 1)
+    for j, s in enumerate(sc):
+        ref = ref + F.conv2d(xt, Wt, padding=s, dilation=s) * torch.tensor(coeffs[1 + j], dtype=torch.float64).reshape(1, -1, 1, 1)
+    assert rel(from_nhwc(torch.from_numpy(outs[0][0]), 2), torch.sigmoid(ref).numpy()) < TOL
