@@ -66,6 +66,14 @@ def load_library():
     elif not _build.is_fresh():
         raise RuntimeError("libian.so does not match the sources under csrc/ (digest stamp differs) and hipcc is not "
                            "available to rebuild it")
+    # Load order matters when PyTorch-ROCm lives in the same process (device buffers, streams, torch.distributed): it ships
+    # its own HIP runtime next to the system one libian links.  With torch's loaded first both work side by side (every
+    # test and bench.py run that way); with libian's loaded first, libian's runtime finds no device once torch has
+    # initialised (measured on the MI355X box: build() followed by smoke() in one process).  So: torch first, if present.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     vp, i32, fp = C.c_void_p, C.c_int32, C.c_void_p
     lib.ian_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]
