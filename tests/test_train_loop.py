@@ -110,6 +110,32 @@ def test_npe_host_steps():
     assert im.dtype == np.uint8 and np.array_equal(im, np.uint8(npe_ops.from_tanh(npe_ops.to_tanh(recon) + mask * delta)))
 
 
+def test_paint_event_composes_the_reference_lines():
+    """npe_ops.paint_event without a device model = NPE.py:204-231 line for line; the latent update follows the reference's
+    order of float32 operations (grad = temp*(1+(x2-x1)); Z -= weight*grad), which is what ian_brush_step reproduces."""
+    rs = np.random.RandomState(5)
+    G = rs.randn(1, 100).astype(np.float32)
+
+    class M:
+        def imgradRGB(self, x1, y1, x2, y2, rgb, z):
+            return G
+
+        def sample_at(self, z):
+            return np.tanh(np.float32(z[:, :1, None, None]) + np.zeros((1, 3, 64, 64), np.float32))
+    Z = rs.randn(10, 10).astype(np.float32)
+    box = (20, 21, 27, 28)
+    Zn, x = npe_ops.paint_event(M(), Z, box, np.zeros((3, 64, 64), np.uint8))
+    grad = G[0].reshape(10, 10) * (1 + (box[2] - box[0]))                       # NPE.py:206 (float32 * python int)
+    want = Z - np.float32(0.05) * grad                                         # NPE.py:209
+    assert Zn.dtype == np.float32 and np.array_equal(Zn, want)
+    assert np.array_equal(x, M().sample_at(want.reshape(1, -1))[0])
+    recon = rs.randint(0, 256, (3, 64, 64)).astype(np.uint8)
+    err = (rs.randn(3, 64, 64) * 0.05).astype(np.float32)
+    Zp, im = npe_ops.paint_event(M(), Z, box, np.zeros((3, 64, 64), np.uint8), recon, err)
+    assert np.array_equal(Zp, want)
+    assert np.array_equal(im, npe_ops.photo_blend_host(M().sample_at(want.reshape(1, -1))[0], recon, err)[0])
+
+
 def test_photo_blend_host_is_the_reference_expression():
     """NPE.py:218-231 written out independently (scipy's gaussian_filter, float64 mask, bare uint8 cast) == photo_blend_host,
     and the separable restatement the HIP kernel follows == scipy bit for bit (also on out-of-range data, which wraps)."""
