@@ -76,13 +76,15 @@ struct TgReduceParams {
   int M, qw_shift, qhw_shift, so, OH, OW, Cout, y_stride;
 };
 
-enum TgConfig { TG_128x128 = 0, TG_128x64 = 1, TG_64x64 = 2, TG_32x128 = 3, TG_256x128 = 4, TG_128x32 = 5, TG_NCONFIG = 6 };
+enum TgConfig { TG_128x128 = 0, TG_128x64 = 1, TG_64x64 = 2, TG_32x128 = 3, TG_256x128 = 4, TG_128x32 = 5,
+                TG_128x128W8 = 6 /* 128x128 tile, 8 waves of 64x32 */, TG_NCONFIG = 7 };
 struct TgShape {
   int bm, bn;
 };
 static inline TgShape tg_shape(int cfg) {
   switch (cfg) {
-    case TG_128x128: return {128, 128};
+    case TG_128x128:
+    case TG_128x128W8: return {128, 128};
     case TG_128x64: return {128, 64};
     case TG_64x64: return {64, 64};
     case TG_32x128: return {32, 128};

@@ -199,10 +199,15 @@ __device__ __forceinline__ void tg_store(const TgParams& p, const TgItem& it, co
 //   2: rotated: the fragments of the last k group are read before the barrier and their MFMAs issued after it,
 //      covering the barrier, the next tile's global-load issue and the first fragment reads of the new buffer
 template <int BM, int BN, int WM, int WN, int VAR>
-__global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
+__global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_kernel(const TgParams p) {
   constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
-  constexpr int A_CH = BM / 32, B_CH = BN / 32;
-  static_assert(WM * WN == 4, "4 waves");
+  // 4 waves (256 threads) or 8 waves (512 threads: the 128x128 tile as 2 x 4 waves of 64x32 -- half the accumulator
+  // registers per wave, so that two workgroups = 16 waves fit a CU like four 64x64 workgroups do, at half their
+  // L2->LDS and LDS->register traffic per FLOP).  RS = tile rows one staging pass of the workgroup covers.
+  constexpr int NT = 64 * WM * WN, RS = NT / 8;
+  constexpr int A_CH = BM / RS, B_CH = BN / RS;
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
+  static_assert(BM % RS == 0 && BN % RS == 0, "tile rows must be a multiple of the staging pass");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                    // [2][BM][36]
   float* Bs = smem + 2 * BM * TG_LDS;  // [2][BN][36]
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
   const int qhw_mask = (1 << p.qhw_shift) - 1, qw_mask = (1 << p.qw_shift) - 1;
 #pragma unroll
   for (int j = 0; j < A_CH; ++j) {
-    const int m = it.m0 + r0 + 32 * j;
+    const int m = it.m0 + r0 + RS * j;
     const int n = m >> p.qhw_shift;
     const int rem = m & qhw_mask;
     const int qy = rem >> p.qw_shift, qx = rem & qw_mask;
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
   const int kpt = p.Cin >> 5;  // K-steps per tap
   const unsigned slab_bytes = (unsigned)p.CoutPad * (unsigned)p.Cin * 4u;
   const unsigned w_row = (unsigned)(((it.n0 + r0) * p.Cin + c4) * 4);
-  const unsigned w_rstep = (unsigned)(32 * p.Cin * 4);
+  const unsigned w_rstep = (unsigned)(RS * p.Cin * 4);
 
   int tap = it.ks0 / kpt;
   int cstep = it.ks0 - tap * kpt;
@@ -279,8 +284,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
   {                                                                                                      \
     float* a_ = As + (buf) * BM * TG_LDS + r0 * TG_LDS + c4;                                             \
     float* b_ = Bs + (buf) * BN * TG_LDS + r0 * TG_LDS + c4;                                             \
-    _Pragma("unroll") for (int j = 0; j < A_CH; ++j) *reinterpret_cast<float4*>(a_ + 32 * j * TG_LDS) = RA[j]; \
-    _Pragma("unroll") for (int j = 0; j < B_CH; ++j) *reinterpret_cast<float4*>(b_ + 32 * j * TG_LDS) = RB[j]; \
+    _Pragma("unroll") for (int j = 0; j < A_CH; ++j) *reinterpret_cast<float4*>(a_ + RS * j * TG_LDS) = RA[j]; \
+    _Pragma("unroll") for (int j = 0; j < B_CH; ++j) *reinterpret_cast<float4*>(b_ + RS * j * TG_LDS) = RB[j]; \
   }
 #define TG_STORE_TILE(buf) TG_STORE_FROM(ra, rb, buf)
 
@@ -307,11 +312,11 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TgParams p) {
     _Pragma("unroll") for (int j = 0; j < A_CH; ++j) {                                                   \
       const int iy = a_iy0[j] + tp.dy, ix = a_ix0[j] + tp.dx;                                            \
       const bool ok = ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);                 \
-      tg_dma16(xrsrc, As3 + ((buf) * BM + wave * 8 + 32 * j) * 32, ok ? a_off[j] + doff : 0xFFFFFFF0u, 0);  \
+      tg_dma16(xrsrc, As3 + ((buf) * BM + wave * 8 + RS * j) * 32, ok ? a_off[j] + doff : 0xFFFFFFF0u, 0);  \
     }                                                                                                    \
     const unsigned wsoff = w_cls + (unsigned)tap * slab_bytes + (unsigned)(cstep << 7);                  \
     _Pragma("unroll") for (int j = 0; j < B_CH; ++j)                                                     \
-      tg_dma16(wrsrc, Bs3 + ((buf) * BN + wave * 8 + 32 * j) * 32, w_row + j * w_rstep, wsoff);          \
+      tg_dma16(wrsrc, Bs3 + ((buf) * BN + wave * 8 + RS * j) * 32, w_row + j * w_rstep, wsoff);          \
     if (++cstep == kpt) {                                                                                \
       cstep = 0;                                                                                         \
       ++tap;                                                                                             \
@@ -617,7 +622,7 @@ static hipError_t launch_var(const TgParams& p, int nitems, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k, dim3(nitems), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(k, dim3(nitems), dim3(64 * WM * WN), lds, s, p);
   return hipGetLastError();
 }
 
@@ -646,6 +651,7 @@ hipError_t launch_tapgemm(int cfg, const TgParams& p, int nitems, hipStream_t s)
     case TG_32x128: return launch_cfg<32, 128, 1, 4>(p, nitems, s);
     case TG_256x128: return launch_cfg<256, 128, 2, 2>(p, nitems, s);
     case TG_128x32: return launch_cfg<128, 32, 4, 1>(p, nitems, s);
+    case TG_128x128W8: return launch_cfg<128, 128, 2, 4>(p, nitems, s);
   }
   return hipErrorInvalidValue;
 }
@@ -671,6 +677,7 @@ hipError_t launch_tapgemm_reduce(int cfg, const TgReduceParams& p, int ntiles, i
     case TG_32x128: return launch_red<32, 128>(p, ntiles, kp, s);
     case TG_256x128: return launch_red<256, 128>(p, ntiles, kp, s);
     case TG_128x32: return launch_red<128, 32>(p, ntiles, kp, s);
+    case TG_128x128W8: return launch_red<128, 128>(p, ntiles, kp, s);
   }
   return hipErrorInvalidValue;
 }
