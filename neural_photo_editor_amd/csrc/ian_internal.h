@@ -77,7 +77,8 @@ struct TgReduceParams {
 };
 
 enum TgConfig { TG_128x128 = 0, TG_128x64 = 1, TG_64x64 = 2, TG_32x128 = 3, TG_256x128 = 4, TG_128x32 = 5,
-                TG_128x128W8 = 6 /* 128x128 tile, 8 waves of 64x32 */, TG_NCONFIG = 7 };
+                TG_128x128W8 = 6 /* 128x128 tile, 8 waves of 64x32 */, TG_128x64W8 = 7 /* 128x64 tile, 8 waves of 32x32 */,
+                TG_NCONFIG = 8 };
 struct TgShape {
   int bm, bn;
 };
@@ -85,7 +86,8 @@ static inline TgShape tg_shape(int cfg) {
   switch (cfg) {
     case TG_128x128:
     case TG_128x128W8: return {128, 128};
-    case TG_128x64: return {128, 64};
+    case TG_128x64:
+    case TG_128x64W8: return {128, 64};
     case TG_64x64: return {64, 64};
     case TG_32x128: return {32, 128};
     case TG_128x32: return {128, 32};

@@ -1225,6 +1225,7 @@ std::vector<TgChoice> tune_candidates(const TgLayer& L, int nimg) {
     cfgs = {TG_128x128, TG_128x64, TG_64x64};
     if (M >= 512 && L.Cout >= 128) cfgs.push_back(TG_256x128);
     if (M >= 512 && L.Cout >= 128) cfgs.push_back(TG_128x128W8);
+    if (M >= 512 && L.Cout >= 64) cfgs.push_back(TG_128x64W8);
   }
   int max_ksteps = 0;
   for (auto& c : L.classes) max_ksteps = std::max(max_ksteps, c.ntaps * (L.Cin / 32));
@@ -2171,7 +2172,7 @@ int ian_autotune(ian_handle* h, int32_t n, int32_t what, void* stream) {
   const bool prof = h->prof;
   h->prof = false;
   const bool verbose = getenv("IAN_DEBUG") != nullptr;
-  static const char* cfg_names[TG_NCONFIG] = {"128x128", "128x64", "64x64", "32x128", "256x128", "128x32", "128x128/8w"};
+  static const char* cfg_names[TG_NCONFIG] = {"128x128", "128x64", "64x64", "32x128", "256x128", "128x32", "128x128/8w", "128x64/8w"};
   TuneCache cache;
   tune_cache_load(cache);
   bool cache_dirty = false;

@@ -652,6 +652,7 @@ hipError_t launch_tapgemm(int cfg, const TgParams& p, int nitems, hipStream_t s)
     case TG_256x128: return launch_cfg<256, 128, 2, 2>(p, nitems, s);
     case TG_128x32: return launch_cfg<128, 32, 4, 1>(p, nitems, s);
     case TG_128x128W8: return launch_cfg<128, 128, 2, 4>(p, nitems, s);
+    case TG_128x64W8: return launch_cfg<128, 64, 4, 2>(p, nitems, s);
   }
   return hipErrorInvalidValue;
 }
@@ -678,6 +679,7 @@ hipError_t launch_tapgemm_reduce(int cfg, const TgReduceParams& p, int ntiles, i
     case TG_256x128: return launch_red<256, 128>(p, ntiles, kp, s);
     case TG_128x32: return launch_red<128, 32>(p, ntiles, kp, s);
     case TG_128x128W8: return launch_red<128, 128>(p, ntiles, kp, s);
+    case TG_128x64W8: return launch_red<128, 64>(p, ntiles, kp, s);
   }
   return hipErrorInvalidValue;
 }

@@ -95,7 +95,7 @@ def test_every_layer_activation(arch):
     assert checked == (5 if arch == "IAN_simple" else 12)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_every_tile_config_and_split_policy(cfg):
     """All tapgemm tile shapes, with and without split-K, give the same answer."""
     m, orc, _ = model_for("IAN_simple")
