@@ -117,6 +117,7 @@ struct Options {
                                      // OFF: measured 3x slower per layer at batch 1 (14 -> 37-48 us) -- the agent-scope release every
                                      // workgroup needs before it bumps the arrival counter is a whole-L2 writeback on gfx950
   int tg_reduce_kp = 4;              // split-K reduce: lanes sharing one output element's slabs when a tile has >= 8 slabs
+  int wg_w8 = 1;                     // tapwgrad: 8-wave 128x128 workgroups (16 waves per CU instead of 8)
   int wg_target_items = 1024;        // tapwgrad: split the pixel range until taps x channel tiles x splits reaches this many workgroups
   int mdc_thin_tile = 1;             // thin MDCL (G_b / B_b and their backward-data) with the input rows staged through LDS
   int dense_gemv = 1;                // batch-1 backward of the dense layer fed by the latent as one GEMV launch
@@ -231,6 +232,7 @@ bool apply_option(Options& o, const std::string& k, int value) {
   else if (k == "dense_gemv") o.dense_gemv = value;
   else if (k == "mdc_thin_tile") o.mdc_thin_tile = value;
   else if (k == "wg_target_items") o.wg_target_items = value;
+  else if (k == "wg_w8") o.wg_w8 = value;
   else return false;
   return true;
 }
@@ -2455,7 +2457,7 @@ int build_wg_schedule(ian_layer* l, int nimg, WgSchedule** out) {
   int bm, bn;
   if (L.Cout <= 32) { S.cfg = WG_32x128; bm = 32; bn = 128; }
   else if (L.Cin <= 32) { S.cfg = WG_128x32; bm = 128; bn = 32; }
-  else { S.cfg = WG_128x128; bm = 128; bn = 128; }
+  else { S.cfg = l->ctx.opt.wg_w8 ? WG_128x128W8 : WG_128x128; bm = 128; bn = 128; }
   const int tiles_co = (std::min(L.CoutPad, round_up(L.Cout, bm)) + bm - 1) / bm;
   const int tiles_ci = (L.Cin + bn - 1) / bn;
   const int ntaps = (int)L.taps.size();

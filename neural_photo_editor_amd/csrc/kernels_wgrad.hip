@@ -33,12 +33,15 @@ __device__ __forceinline__ float4 wg_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 constexpr int WG_BK = 32;  // m rows per K-step
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void tapwgrad_kernel(const WgParams p) {
+__global__ __launch_bounds__(64 * WM * WN) void tapwgrad_kernel(const WgParams p) {
   constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
+  // 4 waves, or 8 waves for the 128x128 tile (2 x 4 waves of 64x32: half the accumulator registers per wave, two
+  // workgroups = 16 waves per CU -- the same occupancy argument as tapgemm's 8-wave tile)
+  constexpr int NT = 64 * WM * WN;
   constexpr int A_TPR = BM / 4, B_TPR = BN / 4;          // threads per tile row (float4 each)
-  constexpr int A_RPP = 256 / A_TPR, B_RPP = 256 / B_TPR;  // rows per pass
+  constexpr int A_RPP = NT / A_TPR, B_RPP = NT / B_TPR;  // rows per pass
   constexpr int A_CH = (WG_BK + A_RPP - 1) / A_RPP, B_CH = (WG_BK + B_RPP - 1) / B_RPP;
-  static_assert(WM * WN == 4, "4 waves");
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                      // [2][32][BM]
   float* Bs = smem + 2 * WG_BK * BM;     // [2][32][BN]
@@ -163,7 +166,7 @@ static hipError_t launch_wg(const WgParams& p, int nitems, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k, dim3(nitems), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(k, dim3(nitems), dim3(64 * WM * WN), lds, s, p);
   return hipGetLastError();
 }
 
@@ -173,6 +176,7 @@ hipError_t launch_tapwgrad(int cfg, const WgParams& p, int nitems, hipStream_t s
     case WG_128x128: return launch_wg<128, 128, 2, 2>(p, nitems, s);
     case WG_32x128: return launch_wg<32, 128, 1, 4>(p, nitems, s);
     case WG_128x32: return launch_wg<128, 32, 4, 1>(p, nitems, s);
+    case WG_128x128W8: return launch_wg<128, 128, 2, 4>(p, nitems, s);
   }
   return hipErrorInvalidValue;
 }

@@ -466,3 +466,28 @@ def test_thin_mdcl_lds_staged_equals_direct(env, cin, monkeypatch):
     for j, s in enumerate(sc):
         ref = ref + F.conv2d(xt, Wt, padding=s, dilation=s) * torch.tensor(coeffs[1 + j], dtype=torch.float64).reshape(1, -1, 1, 1)
     assert rel(from_nhwc(torch.from_numpy(outs[0][0]), 2), torch.sigmoid(ref).numpy()) < TOL
+
+
+@pytest.mark.parametrize("kind", ["conv", "deconv"])
+def test_backward_weight_eight_wave_tile_is_bitwise_the_four_wave_tile(env, kind, monkeypatch):
+    """tapwgrad with 8-wave 128x128 workgroups (default) and with the 4-wave ones (wg_w8=0): every output element
+    accumulates the same products in the same order -> identical weight gradients."""
+    lib, T, k = env
+    n, cin, cout, h = 8, 128, 256, 16
+    rs = np.random.RandomState(123)
+    x = to_nhwc(rs.randn(n, cin, h, h).astype(np.float32))
+    oh = h // 2 if kind == "conv" else h * 2
+    dy = to_nhwc(rs.randn(n, cout, oh, oh).astype(np.float32))
+    W = (rs.randn(*((cout, cin, 5, 5) if kind == "conv" else (cin, cout, 5, 5))) * 0.1).astype(np.float32)
+    outs = []
+    for w8 in (1, 0):
+        monkeypatch.setenv("IAN_OPTS", "wg_w8=%d" % w8)
+        layer = T.Layer(lib, T.K_CONV if kind == "conv" else T.K_DECONV, cin, cout, h, h)
+        params = [torch.from_numpy(W.ravel()).cuda()]
+        layer.set_params(params)
+        g = [torch.zeros_like(params[0])]
+        layer.backward_weight(x, dy, n, g)
+        torch.cuda.synchronize()
+        outs.append(g[0].cpu().numpy())
+        layer.close()
+    assert np.abs(outs[0]).max() > 0 and np.array_equal(outs[0], outs[1])
