@@ -201,6 +201,38 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(L.SlotDesc) == 12
 
 
+def test_headers_are_plain_c_and_ctypes_mirrors_their_structs(tmp_path):
+    """include/ian.h and include/ian_train.h compile as C (gcc -std=c99 -pedantic: what a cgo / ctypes / JNI binding sees), and
+    every ctypes.Structure in lib.py has the size and the field offsets the C compiler gives the header's struct."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    mirrors = {"ian_op_desc": L.OpDesc, "ian_slot_desc": L.SlotDesc, "ian_model_desc": L.ModelDesc, "ian_photo_args": L.PhotoArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ian.h"', '#include "ian_train.h"', 'int main(void) {']
+    for cname, cls in mirrors.items():
+        lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    seen = 0
+    for line in filter(None, out):
+        cname, field, val = line.split()
+        cls = mirrors[cname]
+        if field == "size":
+            assert ctypes.sizeof(cls) == int(val), (cname, ctypes.sizeof(cls), val)
+        else:
+            assert getattr(cls, field).offset == int(val), (cname, field)
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in mirrors.values())
+
+
 def test_model_creation_without_gpu_fails_loudly_not_silently():
     import torch
     if torch.cuda.is_available():
