@@ -1,9 +1,9 @@
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import ian_oracle as O
 from neural_photo_editor_amd import IAN, npe_ops as N
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 m = IAN(os.path.join(ROOT, "neural_photo_editor_amd", "configs", "IAN_simple.py"), True, params=O.make_params("IAN_simple", 1))
 IM = np.uint8((O.make_images(1, seed=0)[0] + 1.0) * 127.5)
 Z = m.encode_images(np.asarray([N.to_tanh(IM)], dtype=np.float32))

@@ -1,10 +1,10 @@
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import ian_oracle as O
 from oracle.torch_twin import TorchTwin
 from neural_photo_editor_amd import IAN
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 torch.set_num_threads(32)
 def rel(a,b): return float(np.abs(np.asarray(a,np.float64)-np.asarray(b,np.float64)).max()/(np.abs(np.asarray(b)).max()+1e-30))
 P = O.make_params("IAN", 1)

@@ -1,9 +1,9 @@
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import ian_oracle as O
 from neural_photo_editor_amd import IAN
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = O.make_params("IAN", 1)
 z = O.make_latents(3, seed=21)
 cfgp = os.path.join(ROOT, "neural_photo_editor_amd", "configs", "IAN.py")

@@ -1,7 +1,7 @@
 """Debug: few-filter MDCL backward-weight (mdc_head_wgrad_kernel) vs float64 autograd across batch / extent."""
 import sys, os
 import numpy as np, torch, torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from neural_photo_editor_amd.lib import load_train_library
 from neural_photo_editor_amd import trainer as T
 lib = load_train_library()

@@ -1,7 +1,7 @@
 """Run on the GPU box: step-by-step comparison of the training step with the float64 CPU twin."""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from oracle import ian_oracle as O
 from oracle.train_twin import TrainTwin, make_train_params
 from neural_photo_editor_amd.trainer import Trainer
