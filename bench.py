@@ -255,72 +255,80 @@ def main():
         roofline = main_r["roofline"]
         edit = None
         if arch == "IAN_simple" and not args.no_edit:
-            z = O.make_latents(1, seed=2)
-            rgb = np.full((1, 3, 64, 64), -1.0, np.float32); rgb[:, 0] = 1.0
-            c1, r1, c2, r2 = 26, 26, 30, 30
-            model.imgradRGB(c1, r1, c2, r2, rgb, z)
-            if not os.environ.get("IAN_NO_AUTOTUNE"):
-                h.autotune(1, 3)
-            lat = []
-            for i in range(120):
-                t = time.perf_counter()
-                g = model.imgradRGB(c1, r1, c2, r2, rgb, z)
-                z = z - 0.05 * g * (1 + (c2 - c1))
-                model.sample_at(z)
-                lat.append((time.perf_counter() - t) * 1e3)
-            lat = np.array(lat[20:])
-            os.environ["IAN_NO_DEC_CACHE"] = "1"   # every call recomputes the decoder forward (2 fwd + 1 bwd per step)
-            lat2 = []
-            for i in range(60):
-                t = time.perf_counter()
-                g = model.imgradRGB(c1, r1, c2, r2, rgb, z)
-                z = z - 0.05 * g * (1 + (c2 - c1))
-                model.sample_at(z)
-                lat2.append((time.perf_counter() - t) * 1e3)
-            del os.environ["IAN_NO_DEC_CACHE"]
-            # photo mode (NPE.py:218-231): brush step + blend; the blend runs on the device chained after the decoder
-            from neural_photo_editor_amd import npe_ops
-            IMG = np.uint8((O.make_images(1, seed=9)[0] + 1.0) * 127.5)
-            RECON = model.sample_at_uint8(model.encode_images(np.asarray([npe_ops.to_tanh(IMG)], dtype=np.float32)))[0]
-            ERROR = npe_ops.to_tanh(np.float32(IMG)) - npe_ops.to_tanh(np.float32(RECON))
-            lat3 = []
-            for i in range(80):
-                t = time.perf_counter()
-                g = model.imgradRGB(c1, r1, c2, r2, rgb, z)
-                z = z - 0.05 * g * (1 + (c2 - c1))
-                model.photo_blend(z, RECON, ERROR)
-                lat3.append((time.perf_counter() - t) * 1e3)
-            # the whole brush event as ONE submission (ian_brush_step: gradient + latent update + decoder, one sync)
-            lat5, lat6 = [], []
-            for i in range(100):
-                t = time.perf_counter()
-                z, _ = model.brush_step(c1, r1, c2, r2, z, RGB=rgb, weight=0.05)
-                lat5.append((time.perf_counter() - t) * 1e3)
-            for i in range(80):
-                t = time.perf_counter()
-                z = model.brush_step(c1, r1, c2, r2, z, RGB=rgb, weight=0.05, image=False, photo=(RECON, ERROR))[0]
-                lat6.append((time.perf_counter() - t) * 1e3)
-            h.set_option("edit_graph", 0)       # the same loop with eager launches (round-1 behaviour) for comparison
-            lat4 = []
-            for i in range(60):
-                t = time.perf_counter()
-                g = model.imgradRGB(c1, r1, c2, r2, rgb, z)
-                z = z - 0.05 * g * (1 + (c2 - c1))
-                model.sample_at(z)
-                lat4.append((time.perf_counter() - t) * 1e3)
-            h.set_option("edit_graph", 1)
-            edit = {"p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)), "steps": len(lat),
-                    "p50_ms_no_forward_cache": float(np.percentile(lat2[10:], 50)),
-                    "p50_ms_eager_launches": float(np.percentile(lat4[10:], 50)),
-                    "p50_ms_photo_mode": float(np.percentile(lat3[20:], 50)),
-                    "p50_ms_one_call": float(np.percentile(lat5[20:], 50)), "p95_ms_one_call": float(np.percentile(lat5[20:], 95)),
-                    "p50_ms_one_call_photo_mode": float(np.percentile(lat6[20:], 50)),
-                    "update": "gradient descent (reference, NPE.py:199-209)",
-                    "calls": "imgradRGB + sample_at through the API.py surface (host numpy in/out); batch-1 host calls replay captured "
-                             "hipGraphs on an internal stream; imgradRGB reuses the decoder activations sample_at left for the same "
-                             "latent; photo mode = imgradRGB + the device blend of NPE.py:218-231 (12 KB uint8 image back); "
-                             "one_call = ian_brush_step: gradient + latent update + decoder (+ blend) in one graph replay, one sync",
-                    "includes": "host<->device copies of z, rgb, image"}
+            try:   # secondary measurement: never let it take the headline number down
+                z = O.make_latents(1, seed=2)
+                rgb = np.full((1, 3, 64, 64), -1.0, np.float32); rgb[:, 0] = 1.0
+                c1, r1, c2, r2 = 26, 26, 30, 30
+                model.imgradRGB(c1, r1, c2, r2, rgb, z)
+                if not os.environ.get("IAN_NO_AUTOTUNE"):
+                    h.autotune(1, 3)
+                lat = []
+                for i in range(120):
+                    t = time.perf_counter()
+                    g = model.imgradRGB(c1, r1, c2, r2, rgb, z)
+                    z = z - 0.05 * g * (1 + (c2 - c1))
+                    model.sample_at(z)
+                    lat.append((time.perf_counter() - t) * 1e3)
+                lat = np.array(lat[20:])
+                os.environ["IAN_NO_DEC_CACHE"] = "1"   # every call recomputes the decoder forward (2 fwd + 1 bwd per step)
+                lat2 = []
+                for i in range(60):
+                    t = time.perf_counter()
+                    g = model.imgradRGB(c1, r1, c2, r2, rgb, z)
+                    z = z - 0.05 * g * (1 + (c2 - c1))
+                    model.sample_at(z)
+                    lat2.append((time.perf_counter() - t) * 1e3)
+                del os.environ["IAN_NO_DEC_CACHE"]
+                # photo mode (NPE.py:218-231): brush step + blend; the blend runs on the device chained after the decoder
+                from neural_photo_editor_amd import npe_ops
+                IMG = np.uint8((O.make_images(1, seed=9)[0] + 1.0) * 127.5)
+                RECON = model.sample_at_uint8(model.encode_images(np.asarray([npe_ops.to_tanh(IMG)], dtype=np.float32)))[0]
+                ERROR = npe_ops.to_tanh(np.float32(IMG)) - npe_ops.to_tanh(np.float32(RECON))
+                lat3 = []
+                for i in range(80):
+                    t = time.perf_counter()
+                    g = model.imgradRGB(c1, r1, c2, r2, rgb, z)
+                    z = z - 0.05 * g * (1 + (c2 - c1))
+                    model.photo_blend(z, RECON, ERROR)
+                    lat3.append((time.perf_counter() - t) * 1e3)
+                # the whole brush event as ONE submission (ian_brush_step: gradient + latent update + decoder, one sync)
+                lat5, lat6 = [], []
+                for i in range(100):
+                    t = time.perf_counter()
+                    z, _ = model.brush_step(c1, r1, c2, r2, z, RGB=rgb, weight=0.05)
+                    lat5.append((time.perf_counter() - t) * 1e3)
+                for i in range(80):
+                    t = time.perf_counter()
+                    z = model.brush_step(c1, r1, c2, r2, z, RGB=rgb, weight=0.05, image=False, photo=(RECON, ERROR))[0]
+                    lat6.append((time.perf_counter() - t) * 1e3)
+                h.set_option("edit_graph", 0)       # the same loop with eager launches (round-1 behaviour) for comparison
+                lat4 = []
+                for i in range(60):
+                    t = time.perf_counter()
+                    g = model.imgradRGB(c1, r1, c2, r2, rgb, z)
+                    z = z - 0.05 * g * (1 + (c2 - c1))
+                    model.sample_at(z)
+                    lat4.append((time.perf_counter() - t) * 1e3)
+                h.set_option("edit_graph", 1)
+                edit = {"p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)), "steps": len(lat),
+                        "p50_ms_no_forward_cache": float(np.percentile(lat2[10:], 50)),
+                        "p50_ms_eager_launches": float(np.percentile(lat4[10:], 50)),
+                        "p50_ms_photo_mode": float(np.percentile(lat3[20:], 50)),
+                        "p50_ms_one_call": float(np.percentile(lat5[20:], 50)), "p95_ms_one_call": float(np.percentile(lat5[20:], 95)),
+                        "p50_ms_one_call_photo_mode": float(np.percentile(lat6[20:], 50)),
+                        "update": "gradient descent (reference, NPE.py:199-209)",
+                        "calls": "imgradRGB + sample_at through the API.py surface (host numpy in/out); batch-1 host calls replay captured "
+                                 "hipGraphs on an internal stream; imgradRGB reuses the decoder activations sample_at left for the same "
+                                 "latent; photo mode = imgradRGB + the device blend of NPE.py:218-231 (12 KB uint8 image back); "
+                                 "one_call = ian_brush_step: gradient + latent update + decoder (+ blend) in one graph replay, one sync",
+                        "includes": "host<->device copies of z, rgb, image"}
+            except Exception as exc:
+                edit = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                os.environ.pop("IAN_NO_DEC_CACHE", None)
+                try:
+                    h.set_option("edit_graph", 1)
+                except Exception:
+                    pass
         host_io = None
         if args.host_io:
             xh = O.make_images(B, seed=100 + rank)
@@ -332,7 +340,10 @@ def main():
                        "note": "host numpy in -> host numpy out per call (pageable memory, PCIe inclusive); never `value`"}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(arch, P, B if arch == "IAN_simple" else 32)
+            try:
+                cpu = cpu_baseline(arch, P, B if arch == "IAN_simple" else 32)
+            except Exception as exc:
+                cpu = {"error": "%s: %s" % (type(exc).__name__, exc)}
         result = {
             "metric": "64x64 IAN reconstructions/sec", "value": value, "unit": "reconstructions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
