@@ -5,14 +5,17 @@ inference graphs of ajbrock/Neural-Photo-Editor, written from the reference's
 model definitions.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` may import this package.
 
-PARITY UNPINNED: the reference's arithmetic lives in Theano + Lasagne
-("development version", README.md:11-12), neither of which can be imported in
-this environment, and the reference ships no tests, golden vectors, trained
-weights or images.  The only reference-derived
-known-answer test is the MADE mask vector (mask_generator.py, see
-``made_masks``); everything else is pinned by self-consistency: this numpy
-restatement vs. the independent torch-CPU twin (``torch_twin.py``), float64
-twins, and finite-difference gradients.
+PINNING: the reference-OWNED arithmetic is pinned by execution -- the reference's
+layers.py / mask_generator.py / IAN.py / IAN_simple.py / API.py / train_IAN.py /
+sample_IAN.py / GANcheckpoints.py run UNMODIFIED on the evaluating Theano/Lasagne
+stand-in of ``oracle/refexec`` and write tests/golden/ref_*.npz
+(tests/golden/make_ref_golden.py); tests/test_reference_pinned.py holds this
+restatement to those fixtures at float64 round-off.  What stays "[recalled]" is
+the third-party primitive layer (Theano "development version" + Lasagne,
+README.md:11-12, cannot be imported here; no trained weights or images exist,
+SURVEY.md section 0 / 8c): conv / transposed-conv / dilated-conv / batch_norm /
+adam conventions and RandomStreams seeding, restated once in
+oracle/refexec/minilasagne.py and once here.
 
 Every function cites the reference lines it restates (paths relative to
 /root/reference).  Lasagne/Theano primitive semantics are "[recalled]" from the
@@ -172,6 +175,22 @@ def made(z, P, name, masks):
     return o + d
 
 
+def made_as_wired(z, P, name, masks):
+    """What ``lasagne.layers.get_output`` actually feeds through a reference MADE layer.
+
+    layers.py:775 assigns ``self.input_layer = MaskedLayer(incoming=z, ...)``, overwriting the attribute
+    ``lasagne.layers.Layer.__init__`` set to ``z``.  Lasagne's ``get_all_layers`` / ``get_output`` follow
+    ``layer.input_layer`` (helper.py: ``layer_inputs = all_outputs[layer.input_layer]``), so the MADE's
+    ``get_output_for`` (layers.py:814-815) receives the OUTPUT of its own first masked layer,
+    h = relu(z.(W0*M0)+b0), and evaluates the whole masked MLP on h:  made(h), not made(z).
+    Established by executing layers.py on the evaluating stand-in (tests/golden/ref_layers.npz 'iaf/*',
+    ref_IAN.npz 'z'); it is the reference's behaviour in API.py:50, sample_IAN.py:94 and train_IAN.py:116,149.
+    """
+    M0 = masks[0]
+    h = act_fn("relu", z @ (P[name + "_input.W"] * M0) + P[name + "_input.b"])
+    return made(h, P, name, masks)
+
+
 def beta_layer(a, b):
     """layers.py:397-408: 2*(alpha/(alpha+beta+1e-8))-1."""
     return 2 * (a / (a + b + a.dtype.type(1e-8))) - 1
@@ -266,8 +285,8 @@ class Oracle:
         if self.arch == "IAN_simple":
             return np.asarray(z, self.dtype)
         z = np.asarray(z, self.dtype)
-        m = made(z, self.P, "l_IAF_mu", self.masks)
-        s = made(z, self.P, "l_IAF_ls", self.masks)
+        m = made_as_wired(z, self.P, "l_IAF_mu", self.masks)   # see made_as_wired: MADE evaluated on its own
+        s = made_as_wired(z, self.P, "l_IAF_ls", self.masks)   # first hidden layer, as the reference graph does
         return (z - m) / np.exp(s)
 
     def encode_images(self, x):

@@ -80,6 +80,9 @@ class TorchTwin:
         return (h @ (P[name + "_output_W.W"] * M1) + P[name + "_output_W.b"]) + \
                (z @ (P[name + "_output_D.W"] * MD) + P[name + "_output_D.b"])
 
+    def made_hidden(self, z, name):  # the MaskedLayer that layers.py:775 leaves in MADE.input_layer
+        return torch.relu(z @ (self.P[name + "_input.W"] * self.masks[0]) + self.P[name + "_input.b"])
+
     def features(self, x):
         h1 = _act("lrelu", self.conv(x, "enc_conv1", True))
         h2 = _act("lrelu", self.bn(self.conv(h1, "enc_conv2"), "bnorm2"))
@@ -97,7 +100,8 @@ class TorchTwin:
     def Z_IAF_fn(self, z):
         if self.arch == "IAN_simple":
             return z
-        return (z - self.made(z, "l_IAF_mu")) / torch.exp(self.made(z, "l_IAF_ls"))
+        # the reference graph feeds each MADE with its own first masked layer's output (ian_oracle.made_as_wired)
+        return (z - self.made(self.made_hidden(z, "l_IAF_mu"), "l_IAF_mu")) / torch.exp(self.made(self.made_hidden(z, "l_IAF_ls"), "l_IAF_ls"))
 
     def encode(self, x):
         return self.Z_IAF_fn(self.Zfn(x))

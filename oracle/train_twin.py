@@ -126,7 +126,9 @@ class TrainTwin:
         return (h @ (P[name + "_output_W.W"] * M1) + P[name + "_output_W.b"]) + (z @ (P[name + "_output_D.W"] * MD) + P[name + "_output_D.b"])
 
     def iaf(self, z0):
-        return (z0 - self.made(z0, "l_IAF_mu")) / torch.exp(self.made(z0, "l_IAF_ls"))
+        # the reference graph feeds each MADE with its own first masked layer's output (ian_oracle.made_as_wired)
+        hid = lambda n: torch.relu(z0 @ (self.P[n + "_input.W"] * self.masks[0]) + self.P[n + "_input.b"])
+        return (z0 - self.made(hid("l_IAF_mu"), "l_IAF_mu")) / torch.exp(self.made(hid("l_IAF_ls"), "l_IAF_ls"))
 
     def encoder(self, x):
         """-> (introspection features [4], enc_conv4 output)"""
