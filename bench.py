@@ -144,7 +144,51 @@ def train_step_bench(batch, rank, world, iters=3):
     return out
 
 
-def main():
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawn_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher around it: re-run this file as N ranks (one per GPU) under
+    torch.distributed.run -- exactly the command line the driver itself uses -- and relay rank 0's JSON line."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def _dry_run(args, rank, world):
+    """The multi-rank control flow without the GPU: rendezvous (IAN_BENCH_BACKEND, default gloo here), barrier,
+    max-over-ranks of the timed region, one JSON line from rank 0 carrying n_gpus = the number of ranks that ran."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("IAN_BENCH_BACKEND", "gloo"), rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    ranks = torch.ones(1, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "64x64 IAN reconstructions/sec", "value": None, "unit": "reconstructions/s", "n_gpus": world,
+                          "ranks_seen": int(ranks.item()), "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(dt.item()) * 1e3,
+                          "dry_run": True, "higher_is_better": True, "scaling": "weak"}))
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -158,13 +202,22 @@ def main():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-batch", type=int, default=128, help="per-GPU minibatch of the training step (config 5: 1024 over 8 GPUs)")
     ap.add_argument("--host-io", action="store_true", help="also time the API.py-style call: host numpy in, host numpy out (PCIe inclusive)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / aggregation plumbing only: no GPU work, value null "
+                                                           "(tests/test_comm.py runs this with 2 gloo ranks on CPU)")
+    args = ap.parse_args(argv)
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return _spawn_ranks(args.gpus, argv)        # no launcher around us: become one
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus=%d" % (args.gpus, world, world), file=sys.stderr)
+    if args.dry_run:
+        return _dry_run(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # IAN_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised on a single-GPU box (ranks share cuda:0)
     backend = os.environ.get("IAN_BENCH_BACKEND", "nccl")
@@ -386,4 +439,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -16,8 +16,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["kernels_tapgemm.hip", "kernels_misc.hip", "kernels_head.hip", "kernels_npe.hip", "kernels_wgrad.hip", "kernels_train.hip", "ian_runtime.cpp", "ian_train_abi.cpp"]
 HEADERS = ["ian_internal.h", os.path.join("..", "..", "include", "ian.h"), os.path.join("..", "..", "include", "ian_train.h")]
-LIB = os.path.join(HERE, "libian.so")
-STAMP = os.path.join(HERE, ".libian.stamp")
+# IAN_ABLATION_BUILD=1 (scripts/ablate_tapgemm.sh only): a SEPARATE library with the timing-only tapgemm ablations
+# compiled in (-DIAN_ABLATION); the product library never contains them.
+ABLATION = bool(os.environ.get("IAN_ABLATION_BUILD"))
+LIB = os.path.join(HERE, "libian_ablation.so" if ABLATION else "libian.so")
+STAMP = os.path.join(HERE, ".libian_ablation.stamp" if ABLATION else ".libian.stamp")
 ARCH = "gfx950"
 
 
@@ -34,6 +37,7 @@ def _digest():
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(ARCH.encode())
+    h.update(b"ablation" if ABLATION else b"")
     return h.hexdigest()
 
 
@@ -79,12 +83,14 @@ def build(force=False, verbose=False):
 def _build_locked(dig, verbose):
     hipcc = _hipcc()
     objs = []
-    bdir = os.path.join(HERE, "build")
+    bdir = os.path.join(HERE, "build_ablation" if ABLATION else "build")
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for src in SOURCES:
         obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
         cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if ABLATION:
+            cmd.insert(1, "-DIAN_ABLATION")
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

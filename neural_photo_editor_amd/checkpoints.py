@@ -74,13 +74,19 @@ def dumps_py2(metadata):
 
 class _MetadataUnpickler(pickle.Unpickler):
     """Only what a metadata dict of train_IAN.py:571 needs: numpy scalar / dtype reconstruction."""
-    _ALLOWED = {("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy", "dtype")}
+    # _codecs.encode: Python 3 protocol<=2 pickles of numpy scalars carry their raw bytes as
+    # ``_codecs.encode(u'...', 'latin1')`` (round-1 archives of this repo stored such a pickle); a pure function.
+    _ALLOWED = {("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy", "dtype"),
+                ("_codecs", "encode")}
 
     def find_class(self, module, name):
         if (module, name) not in self._ALLOWED:
             raise pickle.UnpicklingError("checkpoint metadata may not reference %s.%s" % (module, name))
         if name == "dtype":
             return np.dtype
+        if name == "encode":
+            import codecs
+            return codecs.encode
         from numpy.core.multiarray import scalar   # resolves to numpy._core on numpy >= 2
         return scalar
 

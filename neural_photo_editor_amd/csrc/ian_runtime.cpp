@@ -220,7 +220,15 @@ bool apply_option(Options& o, const std::string& k, int value) {
   else if (k == "tg_xcd_group") o.tg_xcd_group = std::max(1, value);
   else if (k == "tg_prefer_nosplit") o.tg_prefer_nosplit = value;
   else if (k == "tg_nosplit_min_out") o.tg_nosplit_min_out = value;
-  else if (k == "tg_variant") o.tg_variant = value;
+  else if (k == "tg_variant") {
+#ifdef IAN_ABLATION
+    const bool ok = (value >= 0 && value <= 4) || (value >= 10 && value <= 12);
+#else
+    const bool ok = value >= 0 && value <= 4;   // 10..12 are timing-only ablations with wrong results (-DIAN_ABLATION builds only)
+#endif
+    if (!ok) return false;
+    o.tg_variant = value;
+  }
   else if (k == "tg_reduce_kp") o.tg_reduce_kp = value;
   else if (k == "tg_fused_reduce_max_m") o.tg_fused_reduce_max_m = value;
   else if (k == "mdc_head") o.mdc_head = value;

@@ -585,10 +585,15 @@ hipError_t launch_affine(const float* x, float* y, const float* scale, const flo
 // MADE x2 + IAF (IAN.py:127-128; layers.py:641-650, 735-853).  One block (128 threads) per latent row.
 // wts: 6 pre-masked [d][d] matrices (row = input) in the order mu_input, mu_output_W, mu_output_D,
 // ls_input, ls_output_W, ls_output_D; bias: 6 x [d].
+// The graph is the one lasagne.layers.get_output builds from the reference's objects, not the textbook MADE:
+// layers.py:775 overwrites MADE.input_layer with the first MaskedLayer, so get_output (helper.py: all_outputs[
+// layer.input_layer]) hands MADE.get_output_for that layer's OUTPUT and the masked MLP runs on it:
+//   h1 = relu(z.W0+b0);  h2 = relu(h1.W0+b0);  out = (h2.W1+b1) + (h1.WD+bD);  z' = (z - out_mu) / exp(out_ls)
+// (pinned by executing layers.py: tests/golden/ref_layers.npz 'iaf/*', ref_IAN.npz 'z'; needs hidden == d).
 __global__ __launch_bounds__(128) void made_iaf_kernel(const float* __restrict__ z, float* __restrict__ zo,
                                                        const float* __restrict__ wts, const float* __restrict__ bias,
                                                        int d, int zs) {
-  __shared__ float zin[128], hm[128], hl[128];
+  __shared__ float zin[128], hm[128], hl[128], gm[128], gl[128];
   const int t = threadIdx.x, row = blockIdx.x;
   zin[t] = (t < d) ? z[(size_t)row * zs + t] : 0.f;
   __syncthreads();
@@ -602,17 +607,29 @@ __global__ __launch_bounds__(128) void made_iaf_kernel(const float* __restrict__
       al = fmaf(zin[i], wts[3 * dd + i * d + t], al);
     }
   }
-  hm[t] = am > 0.f ? am : 0.f;
-  hl[t] = al > 0.f ? al : 0.f;
+  hm[t] = am > 0.f ? am : 0.f;   // h1 of the mu MADE
+  hl[t] = al > 0.f ? al : 0.f;   // h1 of the ls MADE
+  __syncthreads();
+  am = 0.f, al = 0.f;
+  if (t < d) {
+    am = bias[0 * d + t];
+    al = bias[3 * d + t];
+    for (int i = 0; i < d; ++i) {
+      am = fmaf(hm[i], wts[0 * dd + i * d + t], am);
+      al = fmaf(hl[i], wts[3 * dd + i * d + t], al);
+    }
+  }
+  gm[t] = am > 0.f ? am : 0.f;   // h2
+  gl[t] = al > 0.f ? al : 0.f;
   __syncthreads();
   if (t < d) {
     float om = bias[1 * d + t], dm = bias[2 * d + t];
     float ol = bias[4 * d + t], dl = bias[5 * d + t];
     for (int i = 0; i < d; ++i) {
-      om = fmaf(hm[i], wts[1 * dd + i * d + t], om);
-      dm = fmaf(zin[i], wts[2 * dd + i * d + t], dm);
-      ol = fmaf(hl[i], wts[4 * dd + i * d + t], ol);
-      dl = fmaf(zin[i], wts[5 * dd + i * d + t], dl);
+      om = fmaf(gm[i], wts[1 * dd + i * d + t], om);
+      dm = fmaf(hm[i], wts[2 * dd + i * d + t], dm);
+      ol = fmaf(gl[i], wts[4 * dd + i * d + t], ol);
+      dl = fmaf(hl[i], wts[5 * dd + i * d + t], dl);
     }
     const float mu = om + dm, ls = ol + dl;
     zo[(size_t)row * zs + t] = (zin[t] - mu) / expf(ls);

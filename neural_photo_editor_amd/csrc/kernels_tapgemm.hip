@@ -633,13 +633,15 @@ static hipError_t launch_cfg(const TgParams& p, int nitems, hipStream_t s) {
     case 2: return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);
     case 3: return launch_var<BM, BN, WM, WN, 3>(p, nitems, s);
     case 4: return launch_var<BM, BN, WM, WN, 4>(p, nitems, s);
-    case 10: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 10>(p, nitems, s); break;   // timing-only ablations
-    case 11: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 11>(p, nitems, s); break;
-    case 12: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 12>(p, nitems, s); break;
-    default: break;
+#ifdef IAN_ABLATION   // timing-only ablations whose RESULTS ARE WRONG: never in the shipped library (scripts/ablate_tapgemm.sh
+                      // builds its own copy with -DIAN_ABLATION); a production build rejects the values below
+    case 10: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 10>(p, nitems, s); return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);
+    case 11: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 11>(p, nitems, s); return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);
+    case 12: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 12>(p, nitems, s); return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);
+#endif
+    case 0: return launch_var<BM, BN, WM, WN, 0>(p, nitems, s);
+    default: return hipErrorInvalidValue;   // unknown K-loop schedule: refuse rather than silently pick one
   }
-  if (p.variant >= 10) return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);
-  return launch_var<BM, BN, WM, WN, 0>(p, nitems, s);
 }
 
 hipError_t launch_tapgemm(int cfg, const TgParams& p, int nitems, hipStream_t s) {

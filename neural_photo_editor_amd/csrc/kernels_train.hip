@@ -547,12 +547,14 @@ hipError_t launch_sample_bwd(const float* mu, const float* ls, const float* eps,
 }
 
 // MADE x2 + IAF backward-data (layers.py:641-650, 735-853): z = (z0 - m(z0)) / exp(s(z0)); the MADE parameters are
-// never trained (train_IAN.py:184-194), only dL/dz0 is needed.  wts/bias as in made_iaf_kernel (pre-masked).
-//   u = dz / exp(s);  dz0 = u + Jm^T(-u) + Js^T(-dz*z)
+// never trained (train_IAN.py:184-194), only dL/dz0 is needed.  wts/bias as in made_iaf_kernel (pre-masked), and the
+// same reference wiring: h1 = relu(z0.W0+b0), h2 = relu(h1.W0+b0), out = h2.W1+b1 + h1.WD+bD  (see made_iaf_kernel).
+//   u = dz / exp(s);  v_m = -u;  v_s = -dz*z;   per MADE: dh2 = (W1 v) [h2>0];  dh1 = (W0 dh2 + WD v) [h1>0];
+//   dz0 = u + W0_m dh1_m + W0_s dh1_s
 __global__ __launch_bounds__(128) void made_iaf_bwd_kernel(const float* __restrict__ z0, const float* __restrict__ dz,
                                                            float* __restrict__ dz0, const float* __restrict__ wts,
                                                            const float* __restrict__ bias, int d, int zs) {
-  __shared__ float zin[128], hm[128], hl[128], vm[128], vl[128], dhm[128], dhl[128];
+  __shared__ float zin[128], hm[128], hl[128], gm[128], gl[128], vm[128], vl[128], d2m[128], d2l[128], d1m[128], d1l[128];
   const int t = threadIdx.x, row = blockIdx.x;
   const int dd = d * d;
   zin[t] = (t < d) ? z0[(size_t)row * zs + t] : 0.f;
@@ -569,14 +571,26 @@ __global__ __launch_bounds__(128) void made_iaf_bwd_kernel(const float* __restri
   hm[t] = am > 0.f ? am : 0.f;
   hl[t] = al > 0.f ? al : 0.f;
   __syncthreads();
+  am = 0.f, al = 0.f;
+  if (t < d) {
+    am = bias[0 * d + t];
+    al = bias[3 * d + t];
+    for (int i = 0; i < d; ++i) {
+      am = fmaf(hm[i], wts[0 * dd + i * d + t], am);
+      al = fmaf(hl[i], wts[3 * dd + i * d + t], al);
+    }
+  }
+  gm[t] = am > 0.f ? am : 0.f;
+  gl[t] = al > 0.f ? al : 0.f;
+  __syncthreads();
   float u = 0.f;
   if (t < d) {
     float om = bias[1 * d + t], dm = bias[2 * d + t], ol = bias[4 * d + t], dl = bias[5 * d + t];
     for (int i = 0; i < d; ++i) {
-      om = fmaf(hm[i], wts[1 * dd + i * d + t], om);
-      dm = fmaf(zin[i], wts[2 * dd + i * d + t], dm);
-      ol = fmaf(hl[i], wts[4 * dd + i * d + t], ol);
-      dl = fmaf(zin[i], wts[5 * dd + i * d + t], dl);
+      om = fmaf(gm[i], wts[1 * dd + i * d + t], om);
+      dm = fmaf(hm[i], wts[2 * dd + i * d + t], dm);
+      ol = fmaf(gl[i], wts[4 * dd + i * d + t], ol);
+      dl = fmaf(hl[i], wts[5 * dd + i * d + t], dl);
     }
     const float mu = om + dm, ls = ol + dl;
     const float z = (zin[t] - mu) / expf(ls);
@@ -589,24 +603,35 @@ __global__ __launch_bounds__(128) void made_iaf_bwd_kernel(const float* __restri
     vl[t] = 0.f;
   }
   __syncthreads();
-  // hidden gradients: dh[i] = (sum_j v[j]*W1[i][j]) * (h[i] > 0)
-  float gm = 0.f, gl = 0.f;
+  // dh2[i] = (sum_j v[j]*W1[i][j]) * (h2[i] > 0)
+  float a = 0.f, b = 0.f;
   if (t < d) {
     for (int j = 0; j < d; ++j) {
-      gm = fmaf(vm[j], wts[1 * dd + t * d + j], gm);
-      gl = fmaf(vl[j], wts[4 * dd + t * d + j], gl);
+      a = fmaf(vm[j], wts[1 * dd + t * d + j], a);
+      b = fmaf(vl[j], wts[4 * dd + t * d + j], b);
     }
   }
-  dhm[t] = (hm[t] > 0.f) ? gm : 0.f;
-  dhl[t] = (hl[t] > 0.f) ? gl : 0.f;
+  d2m[t] = (gm[t] > 0.f) ? a : 0.f;
+  d2l[t] = (gl[t] > 0.f) ? b : 0.f;
+  __syncthreads();
+  // dh1[i] = (sum_j dh2[j]*W0[i][j] + v[j]*WD[i][j]) * (h1[i] > 0)
+  a = 0.f, b = 0.f;
+  if (t < d) {
+    for (int j = 0; j < d; ++j) {
+      a = fmaf(d2m[j], wts[0 * dd + t * d + j], a);
+      a = fmaf(vm[j], wts[2 * dd + t * d + j], a);
+      b = fmaf(d2l[j], wts[3 * dd + t * d + j], b);
+      b = fmaf(vl[j], wts[5 * dd + t * d + j], b);
+    }
+  }
+  d1m[t] = (hm[t] > 0.f) ? a : 0.f;
+  d1l[t] = (hl[t] > 0.f) ? b : 0.f;
   __syncthreads();
   if (t < d) {
     float g = u;
     for (int j = 0; j < d; ++j) {
-      g = fmaf(dhm[j], wts[0 * dd + t * d + j], g);
-      g = fmaf(vm[j], wts[2 * dd + t * d + j], g);
-      g = fmaf(dhl[j], wts[3 * dd + t * d + j], g);
-      g = fmaf(vl[j], wts[5 * dd + t * d + j], g);
+      g = fmaf(d1m[j], wts[0 * dd + t * d + j], g);
+      g = fmaf(d1l[j], wts[3 * dd + t * d + j], g);
     }
     dz0[(size_t)row * zs + t] = g;
   }

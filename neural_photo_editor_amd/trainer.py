@@ -304,7 +304,16 @@ class Trainer:
         self._alloc()
         self._dirty = {"enc", "Z", "dec"}
         self._plans, self._works, self._fired, self._buckets = {}, [], set(), None
-        self._ev, self._evlog, self.overlap_log = 0, [], []
+        import collections
+        self._ev, self._evlog = 0, []
+        self.overlap_log = collections.deque(maxlen=256)    # last few steps only (read by tests/test_gpu_dp.py); bounded
+        self._plan_key = {}
+        if (self.n & (self.n - 1)) or (self.comm.world & (self.comm.world - 1)):
+            import logging
+            logging.getLogger(__name__).warning(
+                "per-rank batch %d x world %d is not a power of two: batch-norm statistics are still exact, but the partial-sum "
+                "tree (ian_k_tree_sum) walks them serially and the N-rank step is no longer bit-identical to the 1-rank step",
+                self.n, self.comm.world)
         self.head6 = True                        # RGB-Beta head: R / G_a / B_a forward in one pass (kernels_head.hip)
         self.overlap = True                      # data parallel: all-reduce gradient buckets while backward still runs
         self.side = torch.cuda.Stream() if self.comm.world > 1 else None
@@ -890,6 +899,11 @@ class Trainer:
         self.touched = _WriteLog(self)
         self._which, self._ev, self._evlog, self._fired, self._works = which, 0, [], set(), []
         self._buckets = None
+        # the recorded write order depends on these switches: a plan made under other settings is discarded
+        key = (bool(self.head6), bool(self.exact), bool(self.update_running))
+        if self._plan_key.get(which) != key:
+            self._plans.pop(which, None)
+            self._plan_key[which] = key
         plan = self._plans.get(which) if (self.comm.world > 1 and self.overlap) else None
         if plan is not None:
             self._buckets = plan
@@ -905,7 +919,9 @@ class Trainer:
         for b in self._buckets:
             if b["id"] in self._fired:
                 if any(nm in b["names"] for nm in names):
-                    raise IanTrainError("gradient of %s written after its bucket was handed to the all-reduce" % (names,))
+                    self._plans.pop(self._which, None)          # stale plan: the next step of this kind re-records it
+                    raise IanTrainError("gradient of %s written after its bucket was handed to the all-reduce "
+                                        "(write order changed since the plan was recorded; plan dropped)" % (names,))
             elif b["ready"] == self._ev:
                 self._fire(b)
 
@@ -930,7 +946,9 @@ class Trainer:
         torch = self.torch
         view = self.groups[b["group"]].g[b["lo"]:b["hi"]]
         ev = torch.cuda.Event()
-        ev.record()                                   # after the bucket's last writer on the compute stream
+        # every libian kernel of the step is launched on the legacy default stream (K(lib, 0), Layer(..., stream=0)):
+        # the event must be recorded THERE, whatever torch's current stream is
+        ev.record(torch.cuda.default_stream())        # after the bucket's last writer on the compute stream
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
             w = self.comm.all_reduce_sum(view, async_op=True)
@@ -948,15 +966,19 @@ class Trainer:
         for b in self._buckets:
             if b["id"] not in self._fired:
                 self._fire(b)
-        for rec in self.overlap_log[-len(self._works):]:
-            rec["writes_in_backward"] = self._ev
-        for w in self._works:
-            w.wait()                                   # RCCL: stream-level wait; gloo: host wait
+        if self._works:
+            for rec in list(self.overlap_log)[-len(self._works):]:
+                rec["writes_in_backward"] = self._ev
+        with self.torch.cuda.stream(self.torch.cuda.default_stream()):
+            for w in self._works:
+                w.wait()                               # RCCL: the COMPUTE (default) stream waits; gloo: host wait
         self._works = []
         self._buckets = None
 
     def step(self, which, X, Z, eps, return_metrics=True):
         upd = "dec" if which == "gen" else "enc"
+        if self.dev.type == "cuda" and self.torch.cuda.current_stream() != self.torch.cuda.default_stream():
+            raise IanTrainError("Trainer.step must be called on the default stream (its kernels are launched on stream 0)")
         self.forward(X, Z, eps)
         m = self.metrics() if return_metrics else None
         self.backward(which)

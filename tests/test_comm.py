@@ -81,3 +81,23 @@ def test_replica_sharding_of_the_reconstruction_metric():
     times = [0.016, 0.017]
     value = len(times) * per_rank * steps / max(times)
     assert value == pytest.approx(2 * 64 * 10 / 0.017)
+
+
+def test_bench_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start 2 ranks itself (torch.distributed.run on
+    127.0.0.1), rendezvous, take the max over ranks and print ONE line with n_gpus == 2.  --dry-run keeps the GPU out
+    of it so the control flow is covered on CPU (gloo); the timed HIP legs are the same code after the rendezvous."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    env["IAN_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 3 and out["dry_run"] is True

@@ -68,7 +68,7 @@ def _worker(rank, world, port, out_dir):
             for g in (upd, "Z"):
                 assert torch.equal(first[g], tr.groups[g].g), "overlapped all-reduce changed the %s gradients" % g
                 res["%s/%s" % (which, g)] = tr.groups[g].g.cpu().numpy()
-            log = tr.overlap_log[n_first:]
+            log = list(tr.overlap_log)[n_first:]
             assert len(log) == len(tr._plans[which]) and all(r["which"] == which for r in log)
             early = [r for r in log if r["issued_at_write"] < r["writes_in_backward"]]
             res["%s/early" % which] = np.array([len(early), len(log)])

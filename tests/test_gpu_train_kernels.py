@@ -253,7 +253,10 @@ def test_sampling_iaf_losses_ortho_adam(env):
     z0 = mut + torch.exp(lst) * torch.tensor(eps, dtype=torch.float64)
     W = [torch.tensor(w, dtype=torch.float64) for w in Ws]
     Bv = [torch.tensor(b, dtype=torch.float64) for b in bs]
-    mm = lambda z, o: (torch.relu(z @ W[o] + Bv[o]) @ W[o + 1] + Bv[o + 1]) + (z @ W[o + 2] + Bv[o + 2])
+    # the reference graph runs each masked MLP on its own first hidden layer (layers.py:775 overwrites
+    # MADE.input_layer; oracle.made_as_wired, pinned by tests/golden/ref_layers.npz 'iaf/*')
+    mlp = lambda z, o: (torch.relu(z @ W[o] + Bv[o]) @ W[o + 1] + Bv[o + 1]) + (z @ W[o + 2] + Bv[o + 2])
+    mm = lambda z, o: mlp(torch.relu(z @ W[o] + Bv[o]), o)
     z = (z0 - mm(z0, 0)) / torch.exp(mm(z0, 3))
     dz = rs.randn(n, d).astype(np.float32)
     kl = -0.5 * (1 + 2 * lst - mut ** 2 - torch.exp(2 * lst)).mean()

@@ -183,6 +183,22 @@ def test_metadata_unpickler_refuses_code():
         checkpoints.loads_metadata(np.array(evil))
 
 
+def test_round1_style_metadata_still_loads(tmp_path):
+    """Archives written by round 1 of this repo hold the metadata as a uint8 vector containing a Python-3 protocol-2
+    pickle with an np.float32 learning rate (a `_codecs.encode` global): --resume must keep working on them."""
+    import pickle
+    meta = {"learning_rate": np.float32(1e-3), "epoch": 7, "itr": 123}
+    fname = str(tmp_path / "r1.npz")
+    np.savez_compressed(fname, **{"enc_conv1.b": np.zeros(128, np.float32),
+                                  "metadata": np.frombuffer(pickle.dumps(meta, protocol=2), np.uint8)})
+
+    class Spec:
+        name, shape = "enc_conv1.b", (128,)
+    found, got = checkpoints.load_weights(fname, [Spec])
+    assert got["epoch"] == 7 and got["itr"] == 123 and abs(float(got["learning_rate"]) - 1e-3) < 1e-9
+    assert found["enc_conv1.b"].shape == (128,)
+
+
 # ---- C ABI ---------------------------------------------------------------------------------------------------
 def test_library_builds_loads_and_exports_header_symbols():
     lib = L.load_library()

@@ -223,5 +223,5 @@ def test_fixtures_regenerate_from_the_reference(tmp_path):
     for new, old in (("m.npz", "ref_made_masks.npz"), ("l.npz", "ref_layers.npz"), ("s.npz", "ref_IAN_simple.npz")):
         a, b = np.load(str(tmp_path / new)), load(old)
         assert sorted(a.files) == sorted(b.files)
-        for k in a.files:
-            assert np.array_equal(a[k], b[k]), (old, k)
+        for k in a.files:   # float64 sums may be re-associated between runs (threaded torch-CPU convolutions)
+            assert np.array_equal(a[k], b[k]) or rel(a[k], b[k]) < 1e-11, (old, k)
