@@ -1,8 +1,8 @@
 /* CPU ORACLE (plain C restatement of the hot primitives) -- test infrastructure only, never linked into or called
  * by the product path.  Third, independently written statement of the index conventions the HIP kernels must
  * reproduce (beside oracle/ian_oracle.py in numpy and oracle/torch_twin.py in torch): scalar loops, float32 data,
- * float64 accumulation.  PARITY UNPINNED (see ian_oracle.py): the reference's arithmetic lives in Theano/Lasagne/cuDNN,
- * which cannot run here; every function cites the reference lines it restates.  NCHW layout as in the reference.
+ * float64 accumulation.  Index conventions of the third-party primitives are [recalled] (see ian_oracle.py; the
+ * reference-owned compositions above them are pinned by execution, tests/golden/ref_*.npz); every function cites the reference lines it restates.  NCHW layout as in the reference.
  *
  * Build: make -C oracle   (gcc -O2 -shared -fPIC -> oracle/_ref/libian_primitives.so, git-ignored)
  */

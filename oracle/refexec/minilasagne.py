@@ -31,7 +31,7 @@ import torch
 import torch.nn.functional as F
 
 from . import minitheano as T
-from .minitheano import Variable, SharedVariable, F64
+from .minitheano import Variable, SharedVariable
 
 floatX_name = "float32"
 
@@ -174,12 +174,12 @@ def nnet_relu(x, alpha=0):
 
 def nnet_sigmoid(x):
     x = T.as_tensor_variable(x)
-    return Variable(lambda v: torch.sigmoid(v.to(F64)), [x], x.ndim, floatX_name)
+    return Variable(lambda v: torch.sigmoid(v.to(T.F64)), [x], x.ndim, floatX_name)
 
 
 def nnet_softmax(x):
     x = T.as_tensor_variable(x)
-    return Variable(lambda v: torch.softmax(v.to(F64), dim=-1), [x], x.ndim, floatX_name)
+    return Variable(lambda v: torch.softmax(v.to(T.F64), dim=-1), [x], x.ndim, floatX_name)
 
 
 def categorical_crossentropy(coding_dist, true_dist):
@@ -678,7 +678,7 @@ def _conv2d(x, w, stride, pad, flip, dilation=(1, 1)):
     def f(xv, wv):
         if flip:
             wv = torch.flip(wv, (2, 3))
-        return F.conv2d(xv.to(F64), wv.to(F64), stride=stride, padding=pad, dilation=dilation)
+        return F.conv2d(xv.to(T.F64), wv.to(T.F64), stride=stride, padding=pad, dilation=dilation)
     return Variable(f, [x, w], 4, floatX_name)
 
 
@@ -698,7 +698,7 @@ def _conv2d_grad_input(top, w, stride, pad, flip, out_hw):
         oph, opw = oh - base_h, ow - base_w
         if not (0 <= oph < stride[0] and 0 <= opw < stride[1]):
             raise ValueError("grad-input: requested size %s is inconsistent with the forward convolution" % ((oh, ow),))
-        return F.conv_transpose2d(tv.to(F64), wv.to(F64), stride=stride, padding=pad, output_padding=(oph, opw))
+        return F.conv_transpose2d(tv.to(T.F64), wv.to(T.F64), stride=stride, padding=pad, output_padding=(oph, opw))
     return Variable(f, [top, w] + sym, 4, floatX_name)
 
 
@@ -838,7 +838,7 @@ class DilatedConv2DLayer(BaseConvLayer):
 
         def f(xv, wv):
             # out[b,f,y,x] = sum_c,i,j in[b,c,y+i*d,x+j*d] * W[c,f,i,j]
-            return F.conv2d(xv.to(F64), wv.to(F64).permute(1, 0, 2, 3), dilation=d)
+            return F.conv2d(xv.to(T.F64), wv.to(T.F64).permute(1, 0, 2, 3), dilation=d)
         return Variable(f, [input, self.W], 4, floatX_name)
 
 
@@ -882,7 +882,7 @@ def gpu_alloc_empty(*shape):
 
     def f(*vals):
         it = iter(vals)
-        return torch.zeros([int(next(it)) if isinstance(s, Variable) else int(s) for s in shape], dtype=F64)
+        return torch.zeros([int(next(it)) if isinstance(s, Variable) else int(s) for s in shape], dtype=T.F64)
     v.fn = f
     return v
 

@@ -35,6 +35,13 @@ floatX = "float32"
 _FLOATS = ("float32", "float64", "floatX")
 
 
+def set_float_precision(bits):
+    """64 (default): the float64 "truth".  32: evaluate the SAME graphs in float32 -- used only to measure how far a
+    float32 evaluation of the reference's own graph sits from its float64 evaluation (the conditioning of a comparison)."""
+    global F64
+    F64 = {64: torch.float64, 32: torch.float32}[bits]
+
+
 def _is_float(dt):
     return str(dt).startswith("float")
 

@@ -7,7 +7,7 @@ API.py:59,64 is available through autograd in float32 and float64, and (iii)
 ``bench.py``'s ``cpu_baseline`` leg has a multi-threaded CPU implementation to
 time ("CPU restatement, not Theano").
 
-PARITY UNPINNED (see ian_oracle.py header).  Never imported by the product path.
+PINNED against the reference-executed API.py gradients (tests/golden/ref_IAN*.npz); see ian_oracle.py header.  Never imported by the product path.
 """
 from __future__ import annotations
 

@@ -3,7 +3,8 @@
 A torch-CPU restatement of ``make_training_functions`` (train_IAN.py:47-352) for the full IAN config
 (IAN.py:67-228): the three network passes, the losses, the three parameter groups and the three
 ``lasagne.updates.adam`` instances.  Gradients come from torch autograd, so this twin is independent of the
-hand-written backward kernels it checks.  PARITY UNPINNED (see ian_oracle.py): Theano/Lasagne cannot be run
+hand-written backward kernels it checks.  PINNED against the reference-executed train_IAN.make_training_functions (tests/golden/ref_train_IAN.npz,
+tests/test_reference_pinned.py); third-party primitive conventions [recalled] (see ian_oracle.py): Theano/Lasagne cannot be run
 here; Lasagne semantics are [recalled].
 
 Restated pieces and their reference lines:

@@ -2,7 +2,7 @@
 
 The reference itself cannot run here (no Theano/Lasagne, no weights: SURVEY section 0, 8c), so these are
 outputs of the CPU oracle (oracle/ian_oracle.py float32 restatement, gradients from the torch-CPU twin
-in float64) on seeded synthetic parameters and inputs -- "parity unpinned", they pin the oracle against
+in float64) on seeded synthetic parameters and inputs -- the oracle itself is pinned by the reference-executed fixtures (make_ref_golden.py); these pin it against
 regressions and give the GPU tests fixed targets.  The MADE entries are the one reference-derived
 known answer.   Run:  python tests/golden/make_golden.py
 """

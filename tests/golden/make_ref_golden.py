@@ -305,8 +305,10 @@ def gen_inference(ref, arch, out, tmp):
 
 
 # ------------------------------------------------------------------------------------------------------------
-def gen_train(ref, out, tmp, B=4):
-    """train_IAN.make_training_functions (train_IAN.py:47-352) on the full IAN config, B images per update."""
+def run_train(ref, tmp, B, order=("gen", "discrim")):
+    """train_IAN.make_training_functions (train_IAN.py:47-352) on the full IAN config, B images per update: update_gen on
+    batch 0 then update_discrim on batch 1, as the loop of train_IAN.py:497-504 alternates them.
+    -> dict with metrics, the recorded epsilon draws, every gradient, the parameters after both updates."""
     import lasagne
     P = S.make_train_params(S.make_params("IAN", 1))
     lasagne.random.set_rng(np.random.RandomState(7))
@@ -318,7 +320,6 @@ def gen_train(ref, out, tmp, B=4):
     npz = os.path.join(tmp, "train_params.npz")
     np.savez(npz, **P)
     ref.GANcheckpoints.load_weights(npz, params)
-    t0 = time.time()
     tfuncs, tvars, model = ref.train_IAN.make_training_functions(cfg, model)
     model["l_IAF_mu"].shuffle("Once")   # train_IAN.py:404-405
     model["l_IAF_ls"].shuffle("Once")
@@ -329,62 +330,93 @@ def gen_train(ref, out, tmp, B=4):
     tvars["p1"].set_value(np.asarray([[1, 0, 0]] * len(X), dtype=np.int32))
     tvars["p2"].set_value(np.asarray([[0, 1, 0]] * len(X), dtype=np.int32))
     tvars["p3"].set_value(np.asarray([[0, 0, 1]] * len(X), dtype=np.int32))
-    fx = {"X": X, "Z": Zr, "batch": np.int64(B), "lr": np.float64(tvars["learning_rate"].get_value())}
+    R = {"X": X, "Z": Zr, "P": P, "lr": float(tvars["learning_rate"].get_value()), "grads": {}, "metrics": {}, "eps": {},
+         "metric_names": {"gen": list(tvars["gd"]), "discrim": list(tvars["dd"])}}
     by_name = {p.name: p for p in params}
-    groups = {}
 
     def moments(fn):
-        """{param name: (m shared, beta1)} for the Adam instances inside a compiled update function."""
+        """{param name: m shared} for the Adam instances inside a compiled update function."""
         return {sv.adam_moment_of[0].name: sv for sv in fn.updates if getattr(sv, "adam_moment_of", (0, 0))[1] == "m"}
 
     def counters(fn):
         return [sv for sv in fn.updates if getattr(sv, "adam_step_counter", False)]
 
-    def record(tag, fn, bi, keys, prev_m):
+    prev_m = {}
+    b1 = cfg["beta1"]
+    for bi, tag in enumerate(order):                                                      # itr 0, 1 (:497)
+        fn = tfuncs["update_" + tag]
         vals = fn(bi)
-        fx[tag + "/metrics"] = np.asarray([float(v) for v in vals], np.float64)
-        fx[tag + "/metric_names"] = np.asarray(list(keys))
-        fx[tag + "/eps"] = fn.last_draws[0][1]
+        R["metrics"][tag] = np.asarray([float(v) for v in vals], np.float64)
         assert len(fn.last_draws) == 1
-        ms = moments(fn)
-        groups[tag] = sorted(ms)
-        b1 = cfg["beta1"]
-        for name, sv in ms.items():
-            m_new = sv.get_value_f64()
-            g = (m_new - b1 * prev_m.get(name, 0.0)) / (1 - b1)   # m_t = b1*m_prev + (1-b1)*g
+        R["eps"][tag] = fn.last_draws[0][1]
+        R["grads"][tag] = {}
+        for name, sv in moments(fn).items():
+            m_new = sv.get_value_f64().astype(np.float64)
+            R["grads"][tag][name] = (m_new - b1 * prev_m.get(name, 0.0)) / (1 - b1)   # m_t = b1*m_prev + (1-b1)*g
             prev_m[name] = m_new
+    # the Z group is stepped by both functions through ONE Adam instance (train_IAN.py:266-276)
+    zc = [c for c in counters(tfuncs["update_gen"]) if c in counters(tfuncs["update_discrim"])]
+    assert len(zc) == 1 and float(zc[0].get_value()) == float(len(order))
+    if len(order) == 2:
+        assert all(float(c.get_value()) == 1.0 for c in counters(tfuncs["update_gen"]) + counters(tfuncs["update_discrim"]) if c is not zc[0])
+    R["after"] = {n: p.get_value_f64().astype(np.float64) for n, p in by_name.items()}
+    return R
+
+
+def gen_train(ref, out, tmp, B=4):
+    t0 = time.time()
+    R = run_train(ref, tmp, B)                      # update_gen(0) then update_discrim(1): the alternation of :497-504
+    D = run_train(ref, tmp, B, order=("discrim",))  # update_discrim(0) from the SAME initial parameters ('discrim0')
+    # the SAME reference graph evaluated in float32 (same seeds -> same epsilon): how far float32 arithmetic alone moves
+    # each gradient of a step taken from the initial parameters.  Stored per tensor as 'noise32': the conditioning a
+    # float32 implementation is judged against.  (The second step of a sequence also inherits the trajectory split of
+    # Adam's sign-like first step, so its noise is not a property of the step: 'discrim' carries none.)
+    MT.set_float_precision(32)
+    try:
+        R32 = run_train(ref, tmp, B, order=("gen",))
+        D32 = run_train(ref, tmp, B, order=("discrim",))
+    finally:
+        MT.set_float_precision(64)
+    for src, dst in ((D, R), (D32, R32)):
+        for k in ("grads", "metrics", "eps"):
+            dst[k]["discrim0"] = src[k]["discrim"]
+        dst["metric_names"]["discrim0"] = src["metric_names"]["discrim"]
+    fx = {"X": R["X"], "Z": R["Z"], "batch": np.int64(B), "lr": np.float64(R["lr"])}
+    P = R["P"]
+    rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+    for tag in ("gen", "discrim", "discrim0"):
+        fx[tag + "/metrics"], fx[tag + "/metric_names"], fx[tag + "/eps"] = R["metrics"][tag], np.asarray(R["metric_names"][tag]), R["eps"][tag]
+        fx[tag + "/params"] = np.asarray(sorted(R["grads"][tag]))
+        if tag != "discrim":
+            assert np.array_equal(R["eps"][tag], R32["eps"][tag])
+            fx[tag + "/metrics32"] = R32["metrics"][tag]
+        for name, g in R["grads"][tag].items():
             if g.size <= 4096:
                 fx["%s/grad/%s" % (tag, name)] = g
             else:
                 fx["%s/grad_sample/%s" % (tag, name)], st = sample_of(g, 1024)
                 fx["%s/grad_stat/%s" % (tag, name)] = np.array([st[0], st[1], st[2], np.sqrt((g * g).sum())])
-        return vals
-
-    prev_m = {}
-    g_vals = record("gen", tfuncs["update_gen"], 0, tvars["gd"], prev_m)          # itr 0 -> update_gen (:497)
-    d_vals = record("discrim", tfuncs["update_discrim"], 1, tvars["dd"], prev_m)  # itr 1 -> update_discrim
-    fx["gen/params"] = np.asarray(groups["gen"])
-    fx["discrim/params"] = np.asarray(groups["discrim"])
-    # the Z group is stepped by both functions through ONE Adam instance (train_IAN.py:266-276)
-    zc = [c for c in counters(tfuncs["update_gen"]) if c in counters(tfuncs["update_discrim"])]
-    assert len(zc) == 1 and float(zc[0].get_value()) == 2.0
-    assert all(float(c.get_value()) == 1.0 for c in counters(tfuncs["update_gen"]) + counters(tfuncs["update_discrim"]) if c is not zc[0])
-    trained = sorted(set(groups["gen"]) | set(groups["discrim"]))
+            if tag != "discrim":
+                fx["%s/noise32/%s" % (tag, name)] = np.float64(rel(R32["grads"][tag][name], g))
+    trained = sorted(set(R["grads"]["gen"]) | set(R["grads"]["discrim"]))
     for name in trained:
-        v = by_name[name].get_value_f64()
+        v = R["after"][name]
         if v.size <= 4096:
             fx["after/" + name] = v
         else:
             fx["after_sample/" + name], _ = sample_of(v, 1024)
-    untouched = sorted(n for n in by_name if n not in trained)
+    untouched = sorted(n for n in R["after"] if n not in trained)
     fx["untrained"] = np.asarray(untouched)
     for n in untouched:
         if not (n.endswith(".mean") or n.endswith(".inv_std")):
-            assert np.array_equal(by_name[n].get_value(), P[n]), n
+            assert np.array_equal(R["after"][n].astype(np.float32), P[n]), n
     np.savez_compressed(out, **fx)
     print("train: %.0f s  gen %s  discrim %s" % (time.time() - t0, np.round(fx["gen/metrics"], 5), np.round(fx["discrim/metrics"], 5)))
-    print("  groups: gen %d params, discrim %d params, never trained: %s" % (len(groups["gen"]), len(groups["discrim"]),
-                                                                           [n for n in untouched if "bnorm" not in n and "_bn" not in n][:12]))
+    for tag in ("gen", "discrim0"):
+        nz = np.array([float(fx["%s/noise32/%s" % (tag, n)]) for n in R["grads"][tag]])
+        print("  %s: %d params; float32 evaluation of the reference graph moves the gradients by median %.2e, max %.2e (rel. max-norm)"
+              % (tag, len(nz), np.median(nz), nz.max()))
+    print("  never trained:", [n for n in untouched if "bnorm" not in n and "_bn" not in n][:12])
 
 
 def main(which):

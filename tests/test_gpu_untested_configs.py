@@ -168,7 +168,13 @@ def test_batch_norm_at_the_benchmarked_batch(env, rows_per_image, C, act):
 def test_generator_update_at_the_benchmarked_batch():
     """update_gen's gradients (decoder_params, Z_params: train_IAN.py:256-273) on 128 images vs float64 autograd of the
     twin; the encoder passes on X_hat / X_gen are fed the twin's images, as in test_gpu_train.test_gradients_match_autograd.
-    Measured on MI355X (gpurun_out/diag/composed128.json, round 2): median 5e-5 / worst 9e-3 (decoder), 5e-5 (Z)."""
+    Bars are multiples of what a float32 evaluation of the SAME restatement (torch-CPU twin, float32 vs float64, these
+    inputs; 8 minutes of CPU, so measured once and recorded here) moves each group by -- round 3, with the reference's
+    MADE wiring (oracle.made_as_wired): decoder median 1.74e-3 / worst 5.5e-3, Z median 1.4e-4 / worst 3.2e-3.  (With
+    the textbook MADE of rounds 1-2 the synthetic parameters drove |z| to ~2000 and saturated the decoder, which made
+    the comparison look 50x better conditioned: 3.3e-5 / 9e-3.)
+    Measured on MI355X (gpurun_out/diag/composed128.json, round 3): decoder 3.8e-3 / 3.8e-2, Z 1.25e-4 / 7.1e-3."""
+    TWIN32 = {"dec": (1.74e-3, 5.5e-3), "Z": (1.4e-4, 3.2e-3)}
     from neural_photo_editor_amd.trainer import Trainer
     P = make_train_params(O.make_params("IAN", 1))
     X, Z = O.make_images(NB, seed=31), O.make_latents(NB, seed=32)
@@ -197,8 +203,8 @@ def test_generator_update_at_the_benchmarked_batch():
         errs = sorted(((rel(got[name], r.numpy()), name) for name, r in ref[gname].items()), reverse=True)
         out[gname] = {"median": float(np.median([e for e, _ in errs])), "worst": errs[:5]}
     diag("composed128", out)
-    assert out["dec"]["median"] < 5e-4 and out["dec"]["worst"][0][0] < 3e-2, out["dec"]
-    assert out["Z"]["median"] < 5e-4 and out["Z"]["worst"][0][0] < 1e-3, out["Z"]
+    for gname in ("dec", "Z"):
+        assert out[gname]["median"] < 4 * TWIN32[gname][0] and out[gname]["worst"][0][0] < 10 * TWIN32[gname][1], (gname, out[gname])
 
 
 def test_encoder_passes_at_the_benchmarked_batch():

@@ -195,6 +195,14 @@ def test_train_twin_vs_reference_training_functions():
     m = tw.update_discrim(X[B:], Z[B:], fx["discrim/eps"])
     assert fx["discrim/metric_names"].tolist() == ["discrim_g_loss", "discrim_d_loss", "discrim_acc", "pixel_loss", "pixel_acc"]
     assert rel(m, fx["discrim/metrics"]) < 1e-8
+    # update_discrim taken from the INITIAL parameters (the fixture's 'discrim0'): the step the GPU test holds tight
+    tw0 = TT.TrainTwin(P, dtype=torch.float64)
+    g, _ = tw0.gradients(X[:B], Z[:B], fx["discrim0/eps"])
+    for grp in ("enc", "Z"):
+        for name, gv in g[grp].items():
+            ok, e = _grad_ok(fx, "discrim0", name, gv.numpy(), 1e-7)
+            assert ok, (name, e)
+    assert rel(tw0.update_discrim(X[:B], Z[:B], fx["discrim0/eps"]), fx["discrim0/metrics"]) < 1e-9
     # parameters after the two Adam updates (Z group stepped twice by ONE Adam instance, train_IAN.py:266-276)
     # (Adam's first steps are m/(sqrt(v)+1e-8) ~ sign(g): entries with |g| ~ 1e-8 amplify round-off, hence 2e-6)
     for name in tw.groups["dec"] + tw.groups["Z"] + tw.groups["enc"]:
