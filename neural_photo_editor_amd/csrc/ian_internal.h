@@ -95,6 +95,27 @@ static inline TgShape tg_shape(int cfg) {
   }
 }
 
+// one-image form of the 5x5/s2 transposed conv and of its backward-data (kernels_b1.hip): whole contraction per
+// workgroup (4x4 output positions x 16 channels), weights repacked as one contiguous stream per workgroup
+struct B1Params {
+  const float* x;      // NHWC input of this kernel (activation, or dL/d(pre-epilogue output) for the backward form)
+  const float* w;      // packed [class][channel slice][tap][Cr/32][64 lanes][8]
+  float* y;
+  const float* scale;  // as TgEpilogue
+  const float* shift;
+  const float* yfwd;
+  const float* res;
+  long long cls_off[4];  // float offset of each output-parity class's weights (backward form: one class)
+  int act, bwd, scale_period;
+  int IH, IW, Cr, xs;    // input grid, reduction channels (multiple of 32), input pixel stride
+  int OH, OW, ys;        // output grid and pixel stride
+  int ntiles, tiles_x, nslices;  // 4x4 position blocks (per class), blocks per row, 16-channel output slices
+  unsigned x_bytes;              // extent of x for the buffer descriptor (out-of-range offsets read as zero)
+  int kshift;                    // log2(Cr / 32)
+  int dbg;                       // scripts/ubench/b1conv_bench.cpp only (timing ablations); 0 in the product
+};
+hipError_t launch_b1conv(const B1Params& p, int mode, hipStream_t s);
+
 hipError_t launch_tapgemm(int cfg, const TgParams& p, int nitems, hipStream_t s);
 // kp > 1: four lanes share the slabs of one output element (few tiles, many slabs: batch 1)
 hipError_t launch_tapgemm_reduce(int cfg, const TgReduceParams& p, int ntiles, int kp, hipStream_t s);

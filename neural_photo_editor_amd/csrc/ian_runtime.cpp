@@ -99,6 +99,11 @@ struct OpPlan {
   std::vector<float> h_scale, h_shift;
   float* d_made_w = nullptr;
   float* d_made_b = nullptr;
+  // batch-1 streaming form of a transposed conv and of its backward-data (kernels_b1.hip)
+  std::vector<float> h_b1_fwd, h_b1_bwd;
+  float* d_b1_fwd = nullptr;
+  float* d_b1_bwd = nullptr;
+  long long b1_cls_off[4] = {0, 0, 0, 0};
   long long head_done_serial = -1;  // run_serial of the call in which a sibling's fused head launch produced this op
 };
 
@@ -120,6 +125,9 @@ struct Options {
   int wg_w8 = 1;                     // tapwgrad: 8-wave 128x128 workgroups (16 waves per CU instead of 8)
   int wg_target_items = 1024;        // tapwgrad: split the pixel range until taps x channel tiles x splits reaches this many workgroups
   int mdc_thin_tile = 1;             // thin MDCL (G_b / B_b and their backward-data) with the input rows staged through LDS
+  int b1_conv = 0;                   // batch-1 transposed convs and their backward-data as whole-contraction streaming launches
+                                     // (kernels_b1.hip).  OFF: measured slower than tapgemm + reduce (brush event 0.178 vs 0.160 ms):
+                                     // 16-pixel tiles re-read weights and input rows from L2 at 4 FLOP/B
   int dense_gemv = 1;                // batch-1 backward of the dense layer fed by the latent as one GEMV launch
   int dec_out_px = 1;                // ... and, below that batch, 8 lanes per output pixel instead of 16 tile workgroups
   int dec_out_mfma = 1;              // image-producing deconv (IAN_simple dec_out) on the matrix cores for batches >= 4
@@ -238,6 +246,7 @@ bool apply_option(Options& o, const std::string& k, int value) {
   else if (k == "dec_out_mfma") o.dec_out_mfma = value;
   else if (k == "dec_out_px") o.dec_out_px = value;
   else if (k == "dense_gemv") o.dense_gemv = value;
+  else if (k == "b1_conv") o.b1_conv = value;
   else if (k == "mdc_thin_tile") o.mdc_thin_tile = value;
   else if (k == "wg_target_items") o.wg_target_items = value;
   else if (k == "wg_w8") o.wg_w8 = value;
@@ -489,6 +498,32 @@ int pack_deconv(ian_handle* h, OpPlan& op) {
         for (int ci = 0; ci < cin; ++ci)
           for (int co = 0; co < cout; ++co) dst[(size_t)ci * L.Cin + co] = wref(ci, co, ky, kx);
       }
+  }
+  // batch-1 streaming layouts (kernels_b1.hip): [class][16-channel output slice][tap][32-channel step][lane][8], lane =
+  // (n = l & 15, kg = l >> 4) holding reduction channels step*32 + kg*8 + 0..7 of output channel slice*16 + n
+  if ((cin % 32) == 0 && (cout % 32) == 0 && (H % 4) == 0 && (W % 4) == 0) {
+    op.h_b1_fwd.assign((size_t)25 * cin * cout, 0.f);
+    size_t off = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+      const int py = cls >> 1, px = cls & 1, nky = py ? 2 : 3, nkx = px ? 2 : 3;
+      op.b1_cls_off[cls] = (long long)off;
+      for (int sl = 0; sl < cout / 16; ++sl)
+        for (int t = 0; t < nky * nkx; ++t) {
+          const int ky = py + 2 * (t / nkx), kx = px + 2 * (t % nkx);
+          for (int ks = 0; ks < cin / 32; ++ks, off += 512)
+            for (int l = 0; l < 64; ++l)
+              for (int j = 0; j < 8; ++j)
+                op.h_b1_fwd[off + (size_t)l * 8 + j] = wref(ks * 32 + (l >> 4) * 8 + j, sl * 16 + (l & 15), ky, kx);
+        }
+    }
+    op.h_b1_bwd.assign((size_t)25 * cin * cout, 0.f);
+    off = 0;
+    for (int sl = 0; sl < cin / 16; ++sl)
+      for (int t = 0; t < 25; ++t)
+        for (int ks = 0; ks < cout / 32; ++ks, off += 512)
+          for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j)
+              op.h_b1_bwd[off + (size_t)l * 8 + j] = wref(sl * 16 + (l & 15), ks * 32 + (l >> 4) * 8 + j, t / 5, t % 5);
   }
   return 0;
 }
@@ -1121,6 +1156,34 @@ TgEpilogue fwd_epi(const OpPlan& op, const float* res) {
   return e;
 }
 
+// batch-1 transposed conv / its backward-data as one whole-contraction streaming launch (kernels_b1.hip).
+// mode 0: x = the layer input (H x W x cin), y = its output;  mode 1: x = dL/d(pre-epilogue output) (2H x 2W x cout), y = dL/d(input)
+bool b1_fill(const ian_handle* h, const OpPlan& op, int mode, const Slot& xin, const Slot& yout, B1Params& p) {
+  if (!h->opt.b1_conv || op.d.kind != IAN_OP_DECONV5S2 || op.edge) return false;
+  const float* w = mode == 0 ? op.d_b1_fwd : op.d_b1_bwd;
+  if (!w) return false;
+  const int H = op.d.in_h, W = op.d.in_w, cin = op.d.cin, cout = op.d.cout;
+  p = B1Params();
+  p.w = w;
+  if (mode == 0) {
+    p.IH = H; p.IW = W; p.Cr = cin; p.OH = 2 * H; p.OW = 2 * W;
+    p.nslices = cout / 16;
+    for (int c = 0; c < 4; ++c) p.cls_off[c] = op.b1_cls_off[c];
+  } else {
+    p.IH = 2 * H; p.IW = 2 * W; p.Cr = cout; p.OH = H; p.OW = W;
+    p.nslices = cin / 16;
+  }
+  p.xs = xin.cs; p.ys = yout.cs;
+  if (p.xs < p.Cr || (p.xs & 3)) return false;
+  p.tiles_x = W / 4;
+  p.ntiles = (H / 4) * (W / 4);
+  const size_t xb = (size_t)p.IH * p.IW * p.xs * sizeof(float);
+  if (xb > 0xFFFFFFC0ull) return false;
+  p.x_bytes = (unsigned)xb;
+  p.kshift = ilog2_exact(p.Cr / 32);
+  return p.kshift >= 0;
+}
+
 // ----- forward executor ---------------------------------------------------------------------------------
 int run_op_fwd(ian_handle* h, OpPlan& op, int n, hipStream_t st) {
   Slot& src = h->slots[op.d.src];
@@ -1158,6 +1221,14 @@ int run_op_fwd(ian_handle* h, OpPlan& op, int n, hipStream_t st) {
         HIPCHK(h, launch_deconv_out_nchw(src.d, op.d_edge_w, op.d_scale, op.d_shift, dst.d, n, op.d.in_h, op.d.in_w,
                                          src.cs, op.d.cout, op.d.act, st));
         return 0;
+      }
+      if (n == 1) {
+        B1Params bp;
+        if (b1_fill(h, op, 0, src, dst, bp)) {
+          bp.x = src.d; bp.y = dst.d; bp.scale = op.d_scale; bp.shift = op.d_shift; bp.act = op.d.act; bp.bwd = 0;
+          HIPCHK(h, launch_b1conv(bp, 0, st));
+          return 0;
+        }
       }
       return run_tapgemm(h, op.fwd, n, src.d, dst.d, dst.cs, fwd_epi(op, nullptr), st);
     case IAN_OP_MDC3:
@@ -1547,7 +1618,14 @@ int run_decoder_backward(ian_handle* h, int mode, int c1, int r1, int c2, int r2
             (op.bwd.Cin & 3) == 0 && op.bwd.Cout <= ystride) {
           // the latent's own layer: slab [in][out], row j contiguous in the (permuted) output index = o.g's order
           HIPCHK(h, launch_dense_bwd_gemv(o.g, op.bwd.d_w, op.bwd.Cout, op.bwd.Cin, e.res, in.g, st));
-        } else if ((rc = run_tapgemm(h, op.bwd, 1, o.g, in.g, ystride, e, st))) return rc;
+        } else {
+          B1Params bp;
+          if (kind == IAN_OP_DECONV5S2 && b1_fill(h, op, 1, o, in, bp)) {
+            bp.x = o.g; bp.y = in.g; bp.scale = e.scale; bp.yfwd = e.yfwd; bp.res = e.res; bp.act = e.act; bp.bwd = 1;
+            bp.scale_period = e.scale_period;
+            HIPCHK(h, launch_b1conv(bp, 1, st));
+          } else if ((rc = run_tapgemm(h, op.bwd, 1, o.g, in.g, ystride, e, st))) return rc;
+        }
         touched[op.d.src] = 1;
         if (kind == IAN_OP_MDC3 && op.d.src2 >= 0)  // residual operand of the fused ElemwiseSum: identity edge
           if ((rc = pass_to(o.g, o.cs, 0, op.d.src2, o.c))) return rc;
@@ -1943,6 +2021,10 @@ int ian_finalize(ian_handle* h) {
     if ((rc = upload_layer(h, op.fwd))) return rc;
     if ((rc = upload_layer(h, op.bwd))) return rc;
     if ((rc = upload(h, op.h_edge_w, &op.d_edge_w))) return rc;
+    if ((rc = upload(h, op.h_b1_fwd, &op.d_b1_fwd))) return rc;
+    if ((rc = upload(h, op.h_b1_bwd, &op.d_b1_bwd))) return rc;
+    std::vector<float>().swap(op.h_b1_fwd);
+    std::vector<float>().swap(op.h_b1_bwd);
     if ((rc = upload(h, op.h_scale, &op.d_scale))) return rc;
     if ((rc = upload(h, op.h_shift, &op.d_shift))) return rc;
     std::vector<float>().swap(op.h_edge_w);
@@ -2357,7 +2439,7 @@ void ian_destroy(ian_handle* h) {
       if (L->d_classes) (void)hipFree(L->d_classes);
       if (L->d_taps) (void)hipFree(L->d_taps);
     }
-    for (float* p : {op.d_edge_w, op.d_scale, op.d_shift, op.d_made_w, op.d_made_b})
+    for (float* p : {op.d_edge_w, op.d_scale, op.d_shift, op.d_made_w, op.d_made_b, op.d_b1_fwd, op.d_b1_bwd})
       if (p) (void)hipFree(p);
   }
   for (auto& s : h->slots) {
