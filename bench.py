@@ -30,7 +30,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
-FLOP_PER_RECON = {"IAN_simple": 2.592e9, "IAN": 8.463e9}
+FLOP_PER_RECON = {"IAN_simple": 2.592e9, "IAN": 8.463e9}  # ALGORITHMIC (every MDCL branch counted separately)
+# what the kernels EXECUTE: an MDCL is one composite stencil whose centre tap is shared by its branches (SURVEY App. A:
+# 3298.1 M MAC per decoder instead of 3576.1 M) -> 7.907 GFLOP per full-IAN reconstruction; IAN_simple has no MDCL
+FLOP_EXECUTED = {"IAN_simple": 2.592e9, "IAN": 7.907e9}
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6290 GB/s measured achievable)
+EDIT_STEP_BYTES = 232e6         # one brush event = 2 decoder forwards + 1 backward-data, batch 1, uncached weights
+# train_IAN.py step, FLOP per image: E = encoder + discriminator forward, D = decoder forward (executed);
+# data-gradient and weight-gradient passes each cost one forward.  Both updates run 3 E + 2 D forward (train_IAN.py:116,140,149).
+#   update_gen     backward: decoder x2 passes (data + weight) = 4 D, encoder data-gradient for X_hat and X_gen = 2 E
+#   update_discrim backward: encoder x3 passes (data + weight) = 6 E, + the Z group's path: 1 E (data, X_hat) + 1 D (data)
+E_FLOP, D_FLOP = 2 * 0.6582e9, 2 * 3.2981e9
+TRAIN_FLOP_PER_IMAGE = {"gen": 5 * E_FLOP + 6 * D_FLOP, "discrim": 10 * E_FLOP + 3 * D_FLOP}
 
 
 def _cpu_model_name():
@@ -108,9 +119,15 @@ def pmc_traffic(arch, B):
     if not files:
         return None, None
     try:
+        from neural_photo_editor_amd import build as _b
         with open(files[-1]) as fh:
-            v = json.load(fh).get("tapgemm_traffic_bytes_per_launch")
-        return (float(v) if v else None), os.path.relpath(files[-1], ROOT)
+            js = json.load(fh)
+        v = js.get("tapgemm_traffic_bytes_per_launch")
+        src = os.path.relpath(files[-1], ROOT)
+        if js.get("csrc_digest") != _b._digest():
+            # the profile was taken on other kernel sources than the ones running now: do not quote it as this build's traffic
+            return None, "%s is stale (csrc digest %s != current %s)" % (src, str(js.get("csrc_digest"))[:12], _b._digest()[:12])
+        return (float(v) if v else None), src
     except Exception:
         return None, None
 
@@ -129,15 +146,29 @@ def train_step_bench(batch, rank, world, iters=3):
     out = {}
     if not os.environ.get("IAN_NO_AUTOTUNE"):
         tr.autotune()                                            # untimed: per-layer schedules for this batch on this GPU
+    tr.measure_exposed = world > 1
     for which in ("gen", "discrim"):
-        tr.step(which, X, Z, eps, return_metrics=False)          # warm-up (schedules, workspaces)
+        tr.step(which, X, Z, eps, return_metrics=False)          # warm-up (schedules, workspaces, all-reduce plan)
+        tr.step(which, X, Z, eps, return_metrics=False)          # second warm-up: first step with the overlapped all-reduce
         torch.cuda.synchronize()
+        tr._exposed_events.clear()
         t = time.perf_counter()
         for _ in range(iters):
             tr.step(which, X, Z, eps, return_metrics=False)
         torch.cuda.synchronize()
         out["update_%s_ms" % which] = (time.perf_counter() - t) / iters * 1e3
+    if world > 1:
+        out["allreduce_exposed_ms"] = tr.allreduce_exposed_ms()   # compute-stream stall on the gradient all-reduce, per update kind
     pair = out["update_gen_ms"] + out["update_discrim_ms"]
+    flops = batch * (TRAIN_FLOP_PER_IMAGE["gen"] + TRAIN_FLOP_PER_IMAGE["discrim"])
+    ach = flops / (pair * 1e-3) / 1e12
+    out["roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS, "achieved": ach, "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+                       "traffic": None, "per_gpu": True,
+                       "flop_per_image": {"update_gen": TRAIN_FLOP_PER_IMAGE["gen"], "update_discrim": TRAIN_FLOP_PER_IMAGE["discrim"]},
+                       "frac_update_gen": batch * TRAIN_FLOP_PER_IMAGE["gen"] / (out["update_gen_ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                       "frac_update_discrim": batch * TRAIN_FLOP_PER_IMAGE["discrim"] / (out["update_discrim_ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                       "basis": "executed FLOP of the GEMM-shaped passes (5 E + 6 D per image for update_gen, 10 E + 3 D for update_discrim; "
+                                "E = 1.316 G encoder+discriminator forward, D = 6.596 G decoder forward) over the measured update time"}
     out.update({"images_per_s": 2 * batch * world / (pair * 1e-3), "per_gpu_batch": batch, "global_batch": batch * world,
                 "parallelism": "dp%d, RCCL all-reduce of flat gradient groups, SyncBN statistics + MinibatchLayer all-gather (exact)" % world,
                 "note": "one update_gen + one update_discrim (strict alternation, train_IAN.py:497-504) over synthetic data"})
@@ -290,11 +321,14 @@ def main(argv=None):
             traffic, traffic_src = pmc_traffic(arch, B)
             r["roofline"] = {"bound": "mfma", "kernel": "tapgemm_kernel (fp32 v_mfma_f32_32x32x2_f32)", "achieved": achieved,
                              "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                             "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % traffic_src if traffic else None,
+                             "traffic": traffic, "traffic_unit": ("bytes per launch (rocprofv3 PMC, %s)" % traffic_src) if traffic else traffic_src,
                              "flop_per_launch": flops_per_launch, "launches_per_step": launches / nprof,
                              "avg_launch_ms": avg_ms, "tapgemm_share_of_step": pr["tapgemm_ms"] / max(pr["total_ms"], 1e-9),
-                             "whole_step_tflops": FLOP_PER_RECON[arch] * B / (r["ms_per_step"] * 1e-3) / 1e12,
-                             "whole_step_frac_of_peak": FLOP_PER_RECON[arch] * B / (r["ms_per_step"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+                             "whole_step_tflops": FLOP_EXECUTED[arch] * B / (r["ms_per_step"] * 1e-3) / 1e12,
+                             "whole_step_frac_of_peak": FLOP_EXECUTED[arch] * B / (r["ms_per_step"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                             "whole_step_flop_basis": "executed %.3f GFLOP per reconstruction (algorithmic %.3f: SURVEY 8d counts every MDCL "
+                                                      "branch separately, the kernels run one composite stencil)" % (FLOP_EXECUTED[arch] / 1e9, FLOP_PER_RECON[arch] / 1e9),
+                             "whole_step_frac_algorithmic": FLOP_PER_RECON[arch] * B / (r["ms_per_step"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
         return model, P, r
 
     arch = args.arch
@@ -354,6 +388,17 @@ def main(argv=None):
                     t = time.perf_counter()
                     z = model.brush_step(c1, r1, c2, r2, z, RGB=rgb, weight=0.05, image=False, photo=(RECON, ERROR))[0]
                     lat6.append((time.perf_counter() - t) * 1e3)
+                # BASELINE.json configs[3] words it as an "Adam edit loop" (the reference brush is plain gradient
+                # descent; Adam only exists in training): the same 100-step loop with an Adam update of the latent on the host
+                za, ma, va, lat7 = z.copy(), np.zeros_like(z), np.zeros_like(z), []
+                for i in range(100):
+                    t = time.perf_counter()
+                    g = model.imgradRGB(c1, r1, c2, r2, rgb, za)
+                    ma = 0.9 * ma + 0.1 * g
+                    va = 0.999 * va + 0.001 * g * g
+                    za = (za - 0.01 * (ma / (1 - 0.9 ** (i + 1))) / (np.sqrt(va / (1 - 0.999 ** (i + 1))) + 1e-8)).astype(np.float32)
+                    model.sample_at(za)
+                    lat7.append((time.perf_counter() - t) * 1e3)
                 h.set_option("edit_graph", 0)       # the same loop with eager launches (round-1 behaviour) for comparison
                 lat4 = []
                 for i in range(60):
@@ -370,6 +415,15 @@ def main(argv=None):
                         "p50_ms_one_call": float(np.percentile(lat5[20:], 50)), "p95_ms_one_call": float(np.percentile(lat5[20:], 95)),
                         "p50_ms_one_call_photo_mode": float(np.percentile(lat6[20:], 50)),
                         "update": "gradient descent (reference, NPE.py:199-209)",
+                        "adam_variant": {"p50_ms": float(np.percentile(lat7[20:], 50)), "p95_ms": float(np.percentile(lat7[20:], 95)), "steps": 100,
+                                         "update": "Adam(lr 0.01, 0.9, 0.999) on the host between imgradRGB and sample_at (two calls per step)"},
+                        "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                     "achieved": EDIT_STEP_BYTES / (float(np.percentile(lat5[20:], 50)) * 1e-3) / 1e9,
+                                     "frac": EDIT_STEP_BYTES / (float(np.percentile(lat5[20:], 50)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "traffic": None,
+                                     "basis": "SURVEY 8(d): 232 MB algorithmic per brush event (2 decoder forwards + 1 backward-data at batch 1, "
+                                              "weights uncached) over the p50 of one ian_brush_step call (host copies and the sync included); the "
+                                              "event is latency-bound (13-17 dependent launches), not bandwidth-bound"},
                         "calls": "imgradRGB + sample_at through the API.py surface (host numpy in/out); batch-1 host calls replay captured "
                                  "hipGraphs on an internal stream; imgradRGB reuses the decoder activations sample_at left for the same "
                                  "latent; photo mode = imgradRGB + the device blend of NPE.py:218-231 (12 KB uint8 image back); "
@@ -411,20 +465,25 @@ def main(argv=None):
     if arch == "IAN_simple" and not args.no_full_ian:
         fsteps, fwarm = min(args.steps, 20), min(args.warmup, 5)
         try:
-            fmodel, _, fr = measure("IAN", 256, fsteps, fwarm)
+            fmodel, fP, fr = measure("IAN", 256, fsteps, fwarm)
             fmodel.close()
             del fmodel
             torch.cuda.empty_cache()
             full = {"workload": "IAN (IAN.py: MDBLOCKs + RGB-Beta head + MADE/IAF) encode->z->decode reconstruction, batch 256 per GPU, inputs resident in HBM",
                     "metric": "64x64 IAN reconstructions/sec", "value": fr["value"], "unit": "reconstructions/s", "steps": fsteps, "warmup": fwarm,
                     "ms_per_step": fr["ms_per_step"], "step_ms": fr["step_ms"], "roofline": fr.get("roofline")}
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                try:
+                    full["cpu_baseline"] = cpu_baseline("IAN", fP, 32, budget_s=16.0)
+                except Exception as exc:
+                    full["cpu_baseline"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         except Exception as exc:
             full = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if rank == 0 and result is not None:
             result["full_ian"] = full
     # ---- train_IAN.py step (BASELINE.json configs[4]): full IAN, data parallel, RCCL gradient all-reduce ----------
     train = None
-    if (args.train or world == 1) and not args.no_train:
+    if not args.no_train:   # at N > 1 this is the data-parallel step: 128 images per GPU, SyncBN + MinibatchLayer all-gather ("exact")
         try:
             train = train_step_bench(args.train_batch, rank, world)
         except Exception as exc:  # never let the secondary measurement take the headline number down

@@ -308,6 +308,8 @@ class Trainer:
         self._ev, self._evlog = 0, []
         self.overlap_log = collections.deque(maxlen=256)    # last few steps only (read by tests/test_gpu_dp.py); bounded
         self._plan_key = {}
+        self.measure_exposed = False                     # bench.py: time the compute stream's wait on the gradient all-reduce
+        self._exposed_events = collections.deque(maxlen=64)
         if (self.n & (self.n - 1)) or (self.comm.world & (self.comm.world - 1)):
             import logging
             logging.getLogger(__name__).warning(
@@ -969,9 +971,17 @@ class Trainer:
         if self._works:
             for rec in list(self.overlap_log)[-len(self._works):]:
                 rec["writes_in_backward"] = self._ev
-        with self.torch.cuda.stream(self.torch.cuda.default_stream()):
+        torch = self.torch
+        timed = self.dev.type == "cuda" and self.measure_exposed
+        if timed:                                      # how long the COMPUTE stream stalls on communication: the part of the
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # all-reduce backward did not hide
+            e0.record(torch.cuda.default_stream())
+        with torch.cuda.stream(torch.cuda.default_stream()):
             for w in self._works:
                 w.wait()                               # RCCL: the COMPUTE (default) stream waits; gloo: host wait
+        if timed:
+            e1.record(torch.cuda.default_stream())
+            self._exposed_events.append((which, e0, e1))
         self._works = []
         self._buckets = None
 
@@ -987,6 +997,14 @@ class Trainer:
         self._adam(upd)
         self._adam("Z")
         return m
+
+    def allreduce_exposed_ms(self):
+        """Mean stall of the compute stream on the gradient all-reduce per step kind (needs measure_exposed = True and a
+        device synchronisation before the call)."""
+        out = {}
+        for which, e0, e1 in self._exposed_events:
+            out.setdefault(which, []).append(e0.elapsed_time(e1))
+        return {k: float(sum(v) / len(v)) for k, v in out.items()}
 
     def update_gen(self, X, Z, eps):
         """train_IAN.py:309-318 -> [gen_recon_loss, gen_sample_loss, pixel_loss, feature_loss, pixel_acc]"""

@@ -169,6 +169,11 @@ def main():
                        % (out["tapgemm_traffic_bytes_per_launch"] / 1e6), ""]
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     open(dst + ".md", "w").write("\n".join(md) + "\n")
+    # stamp the kernel sources the profile was taken on: bench.py quotes `tapgemm_traffic_bytes_per_launch` as this
+    # build's roofline.traffic only when the digest matches (otherwise it reports the profile as stale)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from neural_photo_editor_amd import build as _b
+    out["csrc_digest"] = _b._digest()
     json.dump(out, open(dst + ".json", "w"), indent=1)
     print("wrote", dst + ".md", dst + ".json")
 

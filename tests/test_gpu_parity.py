@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = os.path.join(ROOT, "neural_photo_editor_amd", "configs")
 GOLD = os.path.join(ROOT, "tests", "golden")
 TOL = 1e-4        # north-star tolerance on float32 activations
-TOL_GRAD = 5e-4   # gradients: fp32 chain of 5 transposed maps vs a float64 reference
+TOL_GRAD = 1e-5   # brush gradients vs a float64 reference: measured maxima 6.3e-7 (IAN_simple) / 9.4e-7 (IAN) over six patches
+                  # against the reference-executed T.grad (tests/test_gpu_reference_pinned.py, round 3); bar = ~10x that
 
 
 def rel(a, b):
