@@ -2,8 +2,9 @@
  *
  * The reference's training step (train_IAN.py:47-352 make_training_functions) is a Python function that wires
  * Lasagne layers (layers.py: DeconvLayer, MDCL, MinibatchLayer, beta_layer, MADE/IAFLayer; Lasagne: Conv2DDNNLayer,
- * DenseLayer, batch_norm) into one Theano graph and lets Theano differentiate it.  Here the same wiring is done by
- * the Python host (neural_photo_editor_amd/trainer.py) over the entry points below:
+ * DenseLayer, batch_norm) into one Theano graph and lets Theano differentiate it.  Here the same wiring is done -- by
+ * ian_train_step (bottom of this file; csrc/ian_trainer.cpp) for one GPU, and by the Python host
+ * (neural_photo_editor_amd/trainer.py) for the data-parallel step -- over the entry points below:
  *   - ian_layer_*: one object per linear Lasagne layer (conv / transposed conv / MDCL / dense) owning its packed
  *     weights, with forward, backward-data and backward-weight -- the three cuDNN/GEMM calls Theano would emit;
  *   - ian_k_*:     the element-wise / reduction ops around them (batch-statistics batch-norm, activations,
@@ -159,6 +160,51 @@ int ian_k_sum_rows(const float* x, int32_t n, int32_t width, float scale, float*
 int ian_k_ortho(const float* W, float* dW, int32_t A, int32_t B, int32_t K, float c, float* vals, void* stream);
 /* lasagne.updates.adam (App. B.7) on a flat group */
 int ian_k_adam(float* p, const float* g, float* m, float* v, int64_t n, float a_t, float b1, float b2, float eps, void* stream);
+
+/* ---- the whole step behind one entry (ian_train_step) ----------------------------------------------------
+ * ian_trainer owns the full IAN graph of IAN.py:67-228 in training mode: the three Adam groups of train_IAN.py:184-194
+ * (encoder_params, Z_params, decoder_params; reference layouts and Theano names), every activation of the three passes of
+ * train_IAN.py:116-149, the batch-norm running averages and the frozen MADE parameters.  csrc/ian_trainer.cpp wires it
+ * from the entry points above and nothing else; one process, one GPU (the data-parallel step is sequenced by
+ * neural_photo_editor_amd/trainer.py, which has torch.distributed / RCCL at hand). */
+typedef struct ian_trainer ian_trainer;
+typedef struct ian_train_config {
+  int32_t batch;         /* images per update: batch statistics, the MinibatchLayer and the loss means are over exactly this many */
+  int32_t num_latents;   /* cfg['num_latents'] = 100 (IAN.py:52) */
+  int32_t deconv_flip;   /* SURVEY App. B.2 */
+  int32_t reserved;      /* keeps the doubles 8-byte aligned in every ABI */
+  double learning_rate;  /* cfg['learning_rate'][0] = 2e-4 (IAN.py:38); later epochs: ian_trainer_set_option("learning_rate").  double: Adam's
+                            a_t = lr*sqrt(1-b2^t)/(1-b1^t) is formed in double and rounded once, as lasagne.updates.adam's host arithmetic */
+  double beta1;          /* 0.5 (IAN.py:42) */
+  float reg;             /* cfg['reg'] = 1e-5: L2 on Z_params (train_IAN.py:211-213) */
+  float ortho;           /* cfg['ortho'] = 1e-3 (train_IAN.py:214-221); negative: no orthogonal penalty */
+  float recon_weight, feature_weight, dg_weight, dd_weight, agr_weight, ags_weight;   /* IAN.py:53-58 */
+} ian_train_config;
+int ian_trainer_create(const ian_train_config* cfg, ian_trainer** out);
+/* GANcheckpoints.py:33-57: one call per npz entry, Theano parameter names (trainable parameters, "<bn>.mean|inv_std",
+   "l_IAF_{mu,ls}_{input,output_W,output_D}.{W,b}"); host pointer. */
+int ian_trainer_load_param(ian_trainer* t, const char* name, const float* data, int64_t numel);
+/* layers.py:831-853 MADE.shuffle("Once") result (train_IAN.py:404-405): 0/1 masks, (in,out) row-major */
+int ian_trainer_set_made_masks(ian_trainer* t, const float* m0, const float* m1, const float* md, int32_t n);
+int ian_trainer_finalize(ian_trainer* t);
+/* train_IAN.py:309-329.  which 0 = update_gen, 1 = update_discrim (the loop of :497-504 alternates them).  x (n,3,64,64) in
+   [-1,1], zrand (n,100) ~ N(0,1) (:478), eps (n,100) = the GaussianSampleLayer draw (layers.py:433): host or device
+   pointers.  metrics: NULL, or 9 HOST floats of THIS minibatch before the update = discrim_d_loss, gen_recon_loss,
+   gen_sample_loss, discrim_g_loss, discrim_acc, kl_div, pixel_loss, pixel_acc, feature_loss (train_IAN.py:291-304; reading
+   them synchronises `stream`).  0 / negative, text via ian_trainer_last_error. */
+int ian_train_step(ian_trainer* t, int32_t which, const float* x, const float* zrand, const float* eps, int32_t n, float* metrics,
+                   void* stream);
+/* per-layer (tile shape x split-K x K-loop schedule) choice for this batch on this GPU, as ian_layer_autotune */
+int ian_trainer_autotune(ian_trainer* t, void* stream);
+/* copy a parameter / running average (grad = 0) or its gradient of the last step (grad = 1) to the host (checkpoints:
+   train_IAN.py:563-569; tests) */
+int ian_trainer_read_param(ian_trainer* t, const char* name, int32_t grad, float* out, int64_t numel);
+/* "learning_rate" (schedule, train_IAN.py:523-527), "head6", "update_running" */
+int ian_trainer_set_option(ian_trainer* t, const char* key, double value);
+/* Adam step counter of group 0 = encoder_params, 1 = Z_params (stepped by BOTH updates, train_IAN.py:274-276), 2 = decoder_params */
+int32_t ian_trainer_adam_steps(ian_trainer* t, int32_t group);
+const char* ian_trainer_last_error(ian_trainer* t);
+void ian_trainer_destroy(ian_trainer* t);
 
 #ifdef __cplusplus
 }

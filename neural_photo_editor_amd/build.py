@@ -14,7 +14,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["kernels_tapgemm.hip", "kernels_b1.hip", "kernels_misc.hip", "kernels_head.hip", "kernels_npe.hip", "kernels_wgrad.hip", "kernels_train.hip", "ian_runtime.cpp", "ian_train_abi.cpp"]
+SOURCES = ["kernels_tapgemm.hip", "kernels_b1.hip", "kernels_misc.hip", "kernels_head.hip", "kernels_npe.hip", "kernels_wgrad.hip", "kernels_train.hip", "ian_runtime.cpp", "ian_train_abi.cpp", "ian_trainer.cpp"]
 HEADERS = ["ian_internal.h", os.path.join("..", "..", "include", "ian.h"), os.path.join("..", "..", "include", "ian_train.h")]
 # IAN_ABLATION_BUILD=1 (scripts/ablate_tapgemm.sh only): a SEPARATE library with the timing-only tapgemm ablations
 # compiled in (-DIAN_ABLATION); the product library never contains them.

@@ -269,7 +269,7 @@ def parse_header_prototypes(path):
     return out
 
 
-_CT = {"int32_t": C.c_int32, "int64_t": C.c_int64, "float": C.c_float, "int": C.c_int, "ptr": C.c_void_p}
+_CT = {"int32_t": C.c_int32, "int64_t": C.c_int64, "float": C.c_float, "double": C.c_double, "int": C.c_int, "ptr": C.c_void_p}
 
 
 def load_train_library():

@@ -1,0 +1,59 @@
+"""ian_train_step (include/ian_train.h, csrc/ian_trainer.cpp): the whole train_IAN.py update behind one C entry.  It issues
+the same ian_layer_* / ian_k_* launches as trainer.Trainer in the same order, so it must reproduce that step BIT FOR BIT
+(metrics, every gradient, every parameter and running average after the update); trainer.Trainer in turn is held against the
+float64 twin and the reference-executed fixtures by tests/test_gpu_train*.py and tests/test_gpu_reference_pinned.py.  The
+reference-executed metrics are checked here directly as well."""
+import os
+
+import numpy as np
+import pytest
+
+from neural_photo_editor_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "neural_photo_editor_amd", "configs", "IAN.py")
+GOLD = os.path.join(ROOT, "tests", "golden")
+B = 4
+
+
+def test_c_step_is_bitwise_the_python_sequenced_step():
+    import torch
+    from neural_photo_editor_amd.ctrainer import CTrainer, METRICS
+    from neural_photo_editor_amd.trainer import Trainer
+    P = S.make_train_params(S.make_params("IAN", 1))
+    ct, tr = CTrainer(CFG, P, B), Trainer(CFG, P, batch=B)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for it, which in enumerate(("gen", "discrim", "gen", "discrim")):
+        X, Z = S.make_images(B, seed=60 + it), S.make_latents(B, seed=70 + it)
+        eps = np.random.RandomState(80 + it).randn(B, 100).astype(np.float32)
+        mc = ct.step(which, X, Z, eps)                         # host buffers, as a C caller would pass them
+        mp = tr.step(which, dev(X), dev(Z), dev(eps))
+        for k in METRICS:
+            assert mc[k] == np.float32(mp[k]), (it, k, mc[k], mp[k])
+        for gname in (("dec" if which == "gen" else "enc"), "Z"):
+            for name, g in tr.grads_numpy(gname).items():
+                assert np.array_equal(ct.read(name, grad=True), g), (it, name)
+    for name, v in tr.state_dict().items():
+        if not name.startswith("l_IAF_"):
+            assert np.array_equal(ct.read(name), v), name
+    assert ct.adam_steps() == (2, 4, 2)                        # encoder_params, Z_params (both updates), decoder_params
+    moved = np.abs(ct.read("dec_conv1.W") - P["dec_conv1.W"]).mean()
+    assert moved > 0.2 * tr.lr
+    assert np.abs(ct.read("bnorm2.mean") - P["bnorm2.mean"]).max() > 1e-3     # running averages follow the real-data pass
+
+
+def test_c_step_metrics_vs_reference_train_IAN_and_device_pointers():
+    import torch
+    from neural_photo_editor_amd.ctrainer import CTrainer, GEN_KEYS
+    fx = np.load(os.path.join(GOLD, "ref_train_IAN.npz"))
+    P = S.make_train_params(S.make_params("IAN", 1))
+    ct = CTrainer(CFG, P, int(fx["batch"]))
+    b = int(fx["batch"])
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    got = ct.update_gen(dev(fx["X"][:b]), dev(fx["Z"][:b]), dev(fx["gen/eps"]))                # device pointers
+    assert fx["gen/metric_names"].tolist() == list(GEN_KEYS)
+    assert np.allclose(got, fx["gen/metrics"], rtol=2e-4, atol=2e-4), (got, fx["gen/metrics"])
+    with pytest.raises(Exception):
+        ct.step("gen", fx["X"][:2], fx["Z"][:2], fx["gen/eps"][:2])                           # wrong batch: loud
