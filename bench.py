@@ -138,7 +138,12 @@ def train_step_bench(batch, rank, world, iters=3):
     from neural_photo_editor_amd.trainer import Trainer, Comm
     from neural_photo_editor_amd import synthetic as O
     P = O.make_train_params(O.make_params("IAN", 1))
-    tr = Trainer(os.path.join(ROOT, "neural_photo_editor_amd", "configs", "IAN.py"), P, batch=batch, comm=Comm(), exact=True)
+    cfg_path = os.path.join(ROOT, "neural_photo_editor_amd", "configs", "IAN.py")
+    if world == 1:
+        from neural_photo_editor_amd.ctrainer import CTrainer
+        tr = CTrainer(cfg_path, P, batch)              # one GPU: the step is ONE C call (ian_train_step, csrc/ian_trainer.cpp)
+    else:
+        tr = Trainer(cfg_path, P, batch=batch, comm=Comm(), exact=True)   # data parallel: trainer.py sequences the same launches + RCCL
     rs = np.random.RandomState(50 + rank)
     X = torch.from_numpy(O.make_images(batch, seed=200 + rank)).cuda()
     Z = torch.from_numpy(rs.randn(batch, 100).astype(np.float32)).cuda()
@@ -146,12 +151,14 @@ def train_step_bench(batch, rank, world, iters=3):
     out = {}
     if not os.environ.get("IAN_NO_AUTOTUNE"):
         tr.autotune()                                            # untimed: per-layer schedules for this batch on this GPU
-    tr.measure_exposed = world > 1
+    if world > 1:
+        tr.measure_exposed = True
     for which in ("gen", "discrim"):
         tr.step(which, X, Z, eps, return_metrics=False)          # warm-up (schedules, workspaces, all-reduce plan)
         tr.step(which, X, Z, eps, return_metrics=False)          # second warm-up: first step with the overlapped all-reduce
         torch.cuda.synchronize()
-        tr._exposed_events.clear()
+        if world > 1:
+            tr._exposed_events.clear()
         t = time.perf_counter()
         for _ in range(iters):
             tr.step(which, X, Z, eps, return_metrics=False)
@@ -171,6 +178,7 @@ def train_step_bench(batch, rank, world, iters=3):
                                 "E = 1.316 G encoder+discriminator forward, D = 6.596 G decoder forward) over the measured update time"}
     out.update({"images_per_s": 2 * batch * world / (pair * 1e-3), "per_gpu_batch": batch, "global_batch": batch * world,
                 "parallelism": "dp%d, RCCL all-reduce of flat gradient groups, SyncBN statistics + MinibatchLayer all-gather (exact)" % world,
+                "entry": "ian_train_step (C, csrc/ian_trainer.cpp)" if world == 1 else "trainer.Trainer.step (Python-sequenced ian_layer_* / ian_k_* launches + torch.distributed)",
                 "note": "one update_gen + one update_discrim (strict alternation, train_IAN.py:497-504) over synthetic data"})
     return out
 
