@@ -19,8 +19,30 @@ HEADERS = ["ian_internal.h", os.path.join("..", "..", "include", "ian.h"), os.pa
 # IAN_ABLATION_BUILD=1 (scripts/ablate_tapgemm.sh only): a SEPARATE library with the timing-only tapgemm ablations
 # compiled in (-DIAN_ABLATION); the product library never contains them.
 ABLATION = bool(os.environ.get("IAN_ABLATION_BUILD"))
-LIB = os.path.join(HERE, "libian_ablation.so" if ABLATION else "libian.so")
-STAMP = os.path.join(HERE, ".libian_ablation.stamp" if ABLATION else ".libian.stamp")
+# IAN_SANITIZE=1: libian_asan.so -- the HOST translation units of the C-ABI layer (runtime, training ABI, trainer) under
+# AddressSanitizer + UBSan with guard bands around every device allocation (csrc/ian_guard.h); the .hip objects are the
+# product build's.  Loaded by tests through IAN_LIB=<path> with the ASan runtime preloaded (tests/test_sanitize.py).
+SANITIZE = bool(os.environ.get("IAN_SANITIZE")) and not ABLATION
+LIB = os.path.join(HERE, "libian_ablation.so" if ABLATION else ("libian_asan.so" if SANITIZE else "libian.so"))
+STAMP = os.path.join(HERE, ".libian_ablation.stamp" if ABLATION else (".libian_asan.stamp" if SANITIZE else ".libian.stamp"))
+HOST_SOURCES = ("ian_runtime.cpp", "ian_train_abi.cpp", "ian_trainer.cpp")
+# The host units contain no device code (they call the launch_* wrappers of the .hip files), so the sanitized build compiles
+# them with g++ against the HIP runtime API: GCC's ASan runtime, unlike ROCm clang's, does not intercept the HSA allocator
+# (under the ROCm one every process that touches the GPU dies in hsa_amd_memory_pool_allocate on this image).
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-DIAN_SANITIZE", "-D__HIP_PLATFORM_AMD__"]
+
+
+def _rocm_include():
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(_hipcc()))), "include")
+
+
+def asan_runtime():
+    """Path of the ASan runtime to LD_PRELOAD when a non-instrumented executable (python) loads libian_asan.so."""
+    out = subprocess.run(["gcc", "-print-file-name=libasan.so"], stdout=subprocess.PIPE).stdout.decode().strip()
+    out = os.path.realpath(out)
+    if os.path.exists(out) and os.path.isabs(out):
+        return out
+    raise RuntimeError("GCC's libasan.so not found")
 ARCH = "gfx950"
 
 
@@ -38,6 +60,10 @@ def _digest():
             h.update(fh.read())
     h.update(ARCH.encode())
     h.update(b"ablation" if ABLATION else b"")
+    h.update(b"sanitize-g++-libasan" if SANITIZE else b"")
+    if SANITIZE:
+        with open(os.path.join(CSRC, "ian_guard.h"), "rb") as fh:
+            h.update(fh.read())
     return h.hexdigest()
 
 
@@ -91,6 +117,16 @@ def _build_locked(dig, verbose):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if ABLATION:
             cmd.insert(1, "-DIAN_ABLATION")
+        if SANITIZE:
+            if src not in HOST_SOURCES:
+                if not os.path.exists(obj):
+                    raise RuntimeError("IAN_SANITIZE=1 reuses the product build's kernel objects: build libian.so first")
+                objs.append(obj)
+                continue
+            sdir = os.path.join(HERE, "build_asan")
+            os.makedirs(sdir, exist_ok=True)
+            obj = os.path.join(sdir, os.path.splitext(src)[0] + ".o")
+            cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-I" + _rocm_include()] + SAN_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -101,6 +137,9 @@ def _build_locked(dig, verbose):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
     tmp = LIB + ".%d.tmp" % os.getpid()      # never link over a library other ranks may have mapped
     cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs
+    if SANITIZE:
+        gccdir = os.path.dirname(os.path.realpath(subprocess.run(["gcc", "-print-file-name=libasan.so"], stdout=subprocess.PIPE).stdout.decode().strip()))
+        cmd += ["-L" + gccdir, "-lasan", "-lubsan"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stdout.decode(errors="replace"))

@@ -15,6 +15,7 @@
 #include "../../include/ian.h"
 #include "../../include/ian_train.h"
 #include "ian_internal.h"
+#include "ian_guard.h"   // IAN_SANITIZE builds: guard bands around every device allocation (no-op otherwise)
 
 using namespace ian;
 
@@ -2431,6 +2432,7 @@ int ian_set_option(ian_handle* h, const char* key, int32_t value) {
 
 void ian_destroy(ian_handle* h) {
   if (!h) return;
+  IAN_GUARD_CHECK("ian_destroy");
   for (auto& op : h->ops) {
     free_schedules(op.fwd);
     free_schedules(op.bwd);
@@ -2990,6 +2992,7 @@ int ian_layer_autotune(ian_layer* l, int32_t n, float* scratch_a, float* scratch
 }
 
 void ian_layer_destroy(ian_layer* l) {
+  IAN_GUARD_CHECK("ian_layer_destroy");
   if (!l) return;
   if (l->h6_helper) ian_layer_destroy(l->h6_helper);
   for (void* p : {(void*)l->h6_Z, (void*)l->h6_dW, (void*)l->h6_taps})

@@ -4,6 +4,7 @@
 
 #include "../../include/ian_train.h"
 #include "ian_internal.h"
+#include "ian_guard.h"
 
 using namespace ian;
 

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/ian_train.h"
+#include "ian_guard.h"   // IAN_SANITIZE builds: guard bands around every device allocation (no-op otherwise)
 
 namespace {
 
@@ -961,6 +962,7 @@ const char* ian_trainer_last_error(ian_trainer* t) { return t ? t->err.c_str() :
 
 void ian_trainer_destroy(ian_trainer* t) {
   if (!t) return;
+  IAN_GUARD_CHECK("ian_trainer_destroy");
   for (auto& kv : t->layers) ian_layer_destroy(kv.second.l);
   for (float* p : t->allocs)
     if (p) (void)hipFree(p);

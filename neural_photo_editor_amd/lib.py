@@ -59,7 +59,12 @@ def load_library():
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if _build.have_hipcc():
+    override = os.environ.get("IAN_LIB")     # tests/test_sanitize.py: the ASan/UBSan build of the same sources (build.py, IAN_SANITIZE=1)
+    if override:
+        if not os.path.exists(override):
+            raise RuntimeError("IAN_LIB=%s does not exist" % override)
+        path = override
+    elif _build.have_hipcc():
         path = _build.build()      # a compile / link error propagates: never run stale kernels behind a failed build
     elif not os.path.exists(path):
         raise RuntimeError("libian.so is missing and hipcc is not available to build it")

@@ -57,3 +57,23 @@ def test_c_step_metrics_vs_reference_train_IAN_and_device_pointers():
     assert np.allclose(got, fx["gen/metrics"], rtol=2e-4, atol=2e-4), (got, fx["gen/metrics"])
     with pytest.raises(Exception):
         ct.step("gen", fx["X"][:2], fx["Z"][:2], fx["gen/eps"][:2])                           # wrong batch: loud
+
+
+def test_c_step_from_host_buffers_only():
+    """No torch on the device anywhere: numpy in, nine floats out, parameters read back -- what a C caller does.  (Also the
+    scenario tests/test_sanitize.py runs against the ASan/UBSan build: torch's own HIP initialisation does not survive an ASan
+    preload on this image, libian's does.)"""
+    from neural_photo_editor_amd.ctrainer import CTrainer, GEN_KEYS, DISCRIM_KEYS
+    fx = np.load(os.path.join(GOLD, "ref_train_IAN.npz"))
+    b = int(fx["batch"])
+    P = S.make_train_params(S.make_params("IAN", 1))
+    ct = CTrainer(CFG, P, b)
+    got = ct.update_gen(fx["X"][:b], fx["Z"][:b], fx["gen/eps"])
+    assert np.allclose(got, fx["gen/metrics"], rtol=2e-4, atol=2e-4), (got, fx["gen/metrics"])
+    got = np.array(ct.update_discrim(fx["X"][b:], fx["Z"][b:], fx["discrim/eps"]))
+    keep = [i for i, n in enumerate(DISCRIM_KEYS) if n != "discrim_acc"]
+    assert np.allclose(got[keep], fx["discrim/metrics"][keep], rtol=1e-2, atol=1e-3), (got, fx["discrim/metrics"])
+    assert ct.adam_steps() == (1, 2, 1)
+    assert np.abs(ct.read("enc_fc1.W") - P["enc_fc1.W"]).max() > 0            # Z_params moved (both updates)
+    assert np.array_equal(ct.read("bnorm2.mean", grad=False).shape, P["bnorm2.mean"].shape)
+    ct.close()                                                                  # guard bands are verified here in the sanitized build
