@@ -430,7 +430,15 @@ __global__ __launch_bounds__(512, 2) void deconv_small_kernel(DeconvSmallArgs a)
   const int rows_per_band = a.H / a.bands;       // input rows per band (even)
   const int q0 = band * rows_per_band, q1 = q0 + rows_per_band;
   const int oy_lo = 2 * q0, oy_hi = 2 * q1;      // owned output rows
-  const int r_begin = max(0, q0 - 2), r_end = min(a.H, q1 + 2);   // row pairs (even aligned) that reach them
+  // Input rows that reach the owned output rows: q0-1 .. q1 (output row oy collects input rows (oy-2)/2 .. (oy+2)/2), i.e.
+  // ONE halo row per side.  The loop walks row PAIRS from r_begin (any parity): when the count is odd one more row is taken on
+  // the side where the image has one; its contributions all fall outside [oy_lo, oy_hi) and are filtered below.  (Round 2
+  // walked even-aligned pairs from q0-2 to q1+2: 6 pairs per 8-row band instead of 5 -- 17 % of the MFMA and load work.)
+  int r_begin = max(0, q0 - 1), r_end = min(a.H, q1 + 1);
+  if ((r_end - r_begin) & 1) {
+    if (r_begin > 0) --r_begin;
+    else ++r_end;                                                   // r_end <= a.H: a.H is even and r_begin == 0
+  }
 
   float wreg[64];
   {
