@@ -129,6 +129,7 @@ struct Options {
   int b1_conv = 0;                   // batch-1 transposed convs and their backward-data as whole-contraction streaming launches
                                      // (kernels_b1.hip).  OFF: measured slower than tapgemm + reduce (brush event 0.178 vs 0.160 ms):
                                      // 16-pixel tiles re-read weights and input rows from L2 at 4 FLOP/B
+  int alias_io = 1;                  // ian_reconstruct: device-pointer images are read / written in place (no boundary copies)
   int dense_gemv = 1;                // batch-1 backward of the dense layer fed by the latent as one GEMV launch
   int dec_out_px = 1;                // ... and, below that batch, 8 lanes per output pixel instead of 16 tile workgroups
   int dec_out_mfma = 1;              // image-producing deconv (IAN_simple dec_out) on the matrix cores for batches >= 4
@@ -175,6 +176,7 @@ struct ian_handle {
   // the batch-1 decoder activations of the last HOST latent are kept; a gradient call on the same latent skips
   // its forward pass.  Any other use of the decoder slots invalidates it.
   long long run_serial = 0;  // incremented per executed segment (fused head bookkeeping)
+  std::map<int, char> slot_stale;  // external-layout slots whose own buffer was bypassed by a device-pointer call (SlotAlias)
   std::vector<float> dec_cache_z;
   std::vector<float> rgb_cache;  // host copy of the brush image last uploaded to d_rgb
   // NPE.paint photo blend (ian_photo_blend): device copies of RECON / ERROR with their host shadows, outputs
@@ -248,6 +250,7 @@ bool apply_option(Options& o, const std::string& k, int value) {
   else if (k == "dec_out_px") o.dec_out_px = value;
   else if (k == "dense_gemv") o.dense_gemv = value;
   else if (k == "b1_conv") o.b1_conv = value;
+  else if (k == "alias_io") o.alias_io = value;
   else if (k == "mdc_thin_tile") o.mdc_thin_tile = value;
   else if (k == "wg_target_items") o.wg_target_items = value;
   else if (k == "wg_w8") o.wg_w8 = value;
@@ -1425,12 +1428,37 @@ int stage_in(ian_handle* h, const float* src, size_t count, float** buf, size_t*
   return 0;
 }
 
+// A caller's DEVICE buffer stands in for an external-layout slot (l_in / l_out, NCHW) for the duration of one call: the first
+// conv reads the images where they lie and the last op writes the reconstruction where it is wanted -- no boundary copy
+// (2 x 3.1 MB D2D copies = 9 us of the 1.44 ms batch-64 step).  The slot's own buffer is left stale and marked so:
+// ian_read_slot refuses it until a host-pointer call refills it.
+struct SlotAlias {
+  Slot* s = nullptr;
+  float* saved_d = nullptr;
+  size_t saved_cap = 0;
+  void bind(ian_handle* h, int slot, const float* p, int n) {
+    s = &h->slots[slot];
+    saved_d = s->d;
+    saved_cap = s->cap;
+    s->d = const_cast<float*>(p);
+    s->cap = s->per_image() * (size_t)n;
+    h->slot_stale[slot] = 1;
+  }
+  ~SlotAlias() {
+    if (s) {
+      s->d = saved_d;
+      s->cap = saved_cap;
+    }
+  }
+};
+
 int set_image_input(ian_handle* h, const float* x, int n, hipStream_t st) {
   Slot& xs = h->slots[h->desc.x_slot];
   const size_t count = xs.per_image() * (size_t)n;
   int rc;
   if ((rc = ensure_slot(h, h->desc.x_slot, n))) return rc;
   HIPCHK(h, hipMemcpyAsync(xs.d, x, count * sizeof(float), is_device_ptr(x) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  h->slot_stale[h->desc.x_slot] = 0;
   return 0;
 }
 
@@ -1466,6 +1494,7 @@ int get_latent_output(ian_handle* h, int slot, float* z, int n, hipStream_t st) 
 
 int get_image_output(ian_handle* h, float* x, int n, hipStream_t st) {
   Slot& os = h->slots[h->desc.out_slot];
+  h->slot_stale[h->desc.out_slot] = 0;
   const size_t count = os.per_image() * (size_t)n;
   const bool dev = is_device_ptr(x);
   HIPCHK(h, hipMemcpyAsync(x, os.d, count * sizeof(float), dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
@@ -2107,9 +2136,16 @@ int ian_reconstruct(ian_handle* h, const float* x, int32_t n, float* xhat, void*
   enter_stream(h, st);
   TotalTimer tt(h, st);
   h->dec_cache_valid = false;
-  if ((rc = set_image_input(h, x, n, st))) return rc;
+  if (!x || !xhat) return fail(h, -1, "null pointer passed to ian_reconstruct");
+  SlotAlias in_alias, out_alias;
+  if (h->opt.alias_io && is_device_ptr(x) && h->slots[h->desc.x_slot].nchw) in_alias.bind(h, h->desc.x_slot, x, n);
+  else if ((rc = set_image_input(h, x, n, st))) return rc;
   if ((rc = run_segment(h, IAN_SEG_ENC, n, st))) return rc;
   if ((rc = run_segment(h, IAN_SEG_IAF, n, st))) return rc;
+  if (h->opt.alias_io && is_device_ptr(xhat) && h->slots[h->desc.out_slot].nchw && xhat != x) {
+    out_alias.bind(h, h->desc.out_slot, xhat, n);
+    return run_segment(h, IAN_SEG_DEC, n, st);
+  }
   if ((rc = run_segment(h, IAN_SEG_DEC, n, st))) return rc;
   return get_image_output(h, xhat, n, st);
 }
@@ -2359,6 +2395,8 @@ static int read_slot_impl(ian_handle* h, int32_t slot, int32_t n, float* out, vo
     s.nchw = false;
   }
   if (!s.d || s.cap < s.per_image() * (size_t)n) return fail(h, -1, "slot %d holds no %s for batch %d", slot, grad ? "gradient" : "activation", n);
+  if (!grad && h->slot_stale.count(slot) && h->slot_stale[slot])
+    return fail(h, -1, "slot %d was bound to the caller's device buffer in the last call: the library holds no copy of it", slot);
   const size_t count = (size_t)n * s.c * s.h * s.w;
   const bool dev = is_device_ptr(out);
   float* tmp = nullptr;
