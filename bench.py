@@ -164,8 +164,8 @@ def train_step_bench(batch, rank, world, iters=3):
             tr.step(which, X, Z, eps, return_metrics=False)
         torch.cuda.synchronize()
         out["update_%s_ms" % which] = (time.perf_counter() - t) / iters * 1e3
-    if world > 1:
-        out["allreduce_exposed_ms"] = tr.allreduce_exposed_ms()   # compute-stream stall on the gradient all-reduce, per update kind
+        if world > 1:   # compute-stream stall on the gradient all-reduce (what backward did not hide), mean per update of this kind
+            out.setdefault("allreduce_exposed_ms", {}).update(tr.allreduce_exposed_ms())
     pair = out["update_gen_ms"] + out["update_discrim_ms"]
     flops = batch * (TRAIN_FLOP_PER_IMAGE["gen"] + TRAIN_FLOP_PER_IMAGE["discrim"])
     ach = flops / (pair * 1e-3) / 1e12
@@ -177,7 +177,8 @@ def train_step_bench(batch, rank, world, iters=3):
                        "basis": "executed FLOP of the GEMM-shaped passes (5 E + 6 D per image for update_gen, 10 E + 3 D for update_discrim; "
                                 "E = 1.316 G encoder+discriminator forward, D = 6.596 G decoder forward) over the measured update time"}
     out.update({"images_per_s": 2 * batch * world / (pair * 1e-3), "per_gpu_batch": batch, "global_batch": batch * world,
-                "parallelism": "dp%d, RCCL all-reduce of flat gradient groups, SyncBN statistics + MinibatchLayer all-gather (exact)" % world,
+                "parallelism": "dp%d, %s all-reduce of flat gradient groups, SyncBN statistics + MinibatchLayer all-gather (exact)"
+                               % (world, "RCCL" if os.environ.get("IAN_BENCH_BACKEND", "nccl") == "nccl" else os.environ["IAN_BENCH_BACKEND"] + " (test backend)"),
                 "entry": "ian_train_step (C, csrc/ian_trainer.cpp)" if world == 1 else "trainer.Trainer.step (Python-sequenced ian_layer_* / ian_k_* launches + torch.distributed)",
                 "note": "one update_gen + one update_discrim (strict alternation, train_IAN.py:497-504) over synthetic data"})
     return out
