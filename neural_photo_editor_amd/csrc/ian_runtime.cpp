@@ -129,6 +129,7 @@ struct Options {
   int b1_conv = 0;                   // batch-1 transposed convs and their backward-data as whole-contraction streaming launches
                                      // (kernels_b1.hip).  OFF: measured slower than tapgemm + reduce (brush event 0.178 vs 0.160 ms):
                                      // 16-pixel tiles re-read weights and input rows from L2 at 4 FLOP/B
+  int dec_out_wgs = 256;             // image-producing deconv: split images into row bands until this many workgroups exist
   int alias_io = 1;                  // ian_reconstruct: device-pointer images are read / written in place (no boundary copies)
   int dense_gemv = 1;                // batch-1 backward of the dense layer fed by the latent as one GEMV launch
   int dec_out_px = 1;                // ... and, below that batch, 8 lanes per output pixel instead of 16 tile workgroups
@@ -251,6 +252,7 @@ bool apply_option(Options& o, const std::string& k, int value) {
   else if (k == "dense_gemv") o.dense_gemv = value;
   else if (k == "b1_conv") o.b1_conv = value;
   else if (k == "alias_io") o.alias_io = value;
+  else if (k == "dec_out_wgs") o.dec_out_wgs = std::max(1, value);
   else if (k == "mdc_thin_tile") o.mdc_thin_tile = value;
   else if (k == "wg_target_items") o.wg_target_items = value;
   else if (k == "wg_w8") o.wg_w8 = value;
@@ -1211,7 +1213,7 @@ int run_op_fwd(ian_handle* h, OpPlan& op, int n, hipStream_t st) {
         a.x = src.d; a.w = op.d_edge_w; a.scale = op.d_scale; a.shift = op.d_shift; a.y = dst.d;
         a.H = op.d.in_h; a.W = op.d.in_w; a.xs = src.cs; a.act = op.d.act;
         int bands = 1;
-        while (n * bands < 256 && bands < 8 && (op.d.in_h % (4 * bands)) == 0) bands *= 2;   // 2 halo row pairs per band
+        while (n * bands < h->opt.dec_out_wgs && bands < 8 && (op.d.in_h % (4 * bands)) == 0) bands *= 2;   // one halo row per side of a band
         a.bands = bands;
         HIPCHK(h, launch_deconv_small(a, n, op.d.cout, st));
         return 0;
