@@ -15,7 +15,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["kernels_tapgemm.hip", "kernels_b1.hip", "kernels_misc.hip", "kernels_head.hip", "kernels_npe.hip", "kernels_wgrad.hip", "kernels_train.hip", "ian_runtime.cpp", "ian_train_abi.cpp", "ian_trainer.cpp"]
-HEADERS = ["ian_internal.h", os.path.join("..", "..", "include", "ian.h"), os.path.join("..", "..", "include", "ian_train.h")]
+HEADERS = ["ian_internal.h", "ian_guard.h", "ian_rt_types.h", "ian_rt_util.inc", "ian_rt_pack.inc", "ian_rt_schedule.inc", "ian_rt_exec.inc",
+           "ian_rt_autotune.inc", "ian_rt_io.inc", "ian_rt_backward.inc", "ian_rt_edit.inc", "ian_rt_api.inc", "ian_rt_layer.inc", os.path.join("..", "..", "include", "ian.h"), os.path.join("..", "..", "include", "ian_train.h")]
 # IAN_ABLATION_BUILD=1 (scripts/ablate_tapgemm.sh only): a SEPARATE library with the timing-only tapgemm ablations
 # compiled in (-DIAN_ABLATION); the product library never contains them.
 ABLATION = bool(os.environ.get("IAN_ABLATION_BUILD"))
@@ -61,9 +62,7 @@ def _digest():
     h.update(ARCH.encode())
     h.update(b"ablation" if ABLATION else b"")
     h.update(b"sanitize-g++-libasan" if SANITIZE else b"")
-    if SANITIZE:
-        with open(os.path.join(CSRC, "ian_guard.h"), "rb") as fh:
-            h.update(fh.read())
+
     return h.hexdigest()
 
 
