@@ -199,7 +199,9 @@ int ian_trainer_autotune(ian_trainer* t, void* stream);
 /* copy a parameter / running average (grad = 0) or its gradient of the last step (grad = 1) to the host (checkpoints:
    train_IAN.py:563-569; tests) */
 int ian_trainer_read_param(ian_trainer* t, const char* name, int32_t grad, float* out, int64_t numel);
-/* "learning_rate" (schedule, train_IAN.py:523-527), "head6", "update_running" */
+/* "learning_rate" (schedule, train_IAN.py:523-527), "head6", "update_running"; "overlap_wgrad" (default 1): weight-gradient
+   GEMMs go to a second HIP stream owned by the trainer and are joined before the regularizers and Adam -- same launches, same
+   numbers, bitwise (tests/test_gpu_ctrainer.py); 0 keeps everything on the caller's stream */
 int ian_trainer_set_option(ian_trainer* t, const char* key, double value);
 /* Adam step counter of group 0 = encoder_params, 1 = Z_params (stepped by BOTH updates, train_IAN.py:274-276), 2 = decoder_params */
 int32_t ian_trainer_adam_steps(ian_trainer* t, int32_t group);

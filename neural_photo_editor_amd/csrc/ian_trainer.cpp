@@ -112,6 +112,14 @@ struct ian_trainer {
   const float* eps = nullptr;
   int head6 = 1, update_running = 1;
   hipStream_t st = nullptr;
+  // weight-gradient GEMMs (ian_layer_backward_weight: 19 % of the step) are off the critical path -- nothing reads a gradient
+  // before the regularisers -- so they are issued on a second stream behind an event on the compute stream (their dy operand
+  // is final at that point and is not written again in the same sweep) and overlap the element-wise kernels of the
+  // backward-data chain; the compute stream joins before the regularisers.  Same launches, same per-parameter order.
+  int overlap_wgrad = 1;
+  hipStream_t st2 = nullptr;
+  std::vector<hipEvent_t> events;
+  size_t ev_used = 0;
 };
 
 namespace {
@@ -407,11 +415,41 @@ int bn_backward(ian_trainer* t, BN& bn, const float* dA, const float* a, const f
   TK(ian_k_bn_bwd(dA, a, y, bn.mean, bn.inv_std, bn.scale, bn.bsums, bn.count, dy, rows, C, stride, act, t->st));
   return 0;
 }
+int side_stream(ian_trainer* t, hipStream_t* out) {  // the stream a weight-gradient launch goes to, ordered behind what is on t->st now
+  *out = t->st;
+  if (!t->overlap_wgrad || !t->st2) return 0;
+  if (t->ev_used == t->events.size()) {
+    hipEvent_t e;
+    THIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    t->events.push_back(e);
+  }
+  hipEvent_t e = t->events[t->ev_used++];
+  THIP(hipEventRecord(e, t->st));
+  THIP(hipStreamWaitEvent(t->st2, e, 0));
+  *out = t->st2;
+  return 0;
+}
+int join_side_stream(ian_trainer* t) {  // the compute stream waits for every weight gradient issued so far
+  if (!t->overlap_wgrad || !t->st2 || !t->ev_used) return 0;
+  if (t->ev_used == t->events.size()) {
+    hipEvent_t e;
+    THIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    t->events.push_back(e);
+  }
+  hipEvent_t e = t->events[t->ev_used++];
+  THIP(hipEventRecord(e, t->st2));
+  THIP(hipStreamWaitEvent(t->st, e, 0));
+  t->ev_used = 0;
+  return 0;
+}
 int wgrad(ian_trainer* t, const std::string& lname, const float* x, const float* dy) {
   LayerRef& r = t->layers.at(lname);
   std::vector<float*> g;
   for (auto& p : r.pnames) g.push_back(G(t, p));
-  TL(r.l, ian_layer_backward_weight(r.l, x, dy, t->n, g.data(), (int)g.size(), t->touched.count(r.pnames[0]) ? 1 : 0, t->st));
+  hipStream_t ws;
+  int rc_ = side_stream(t, &ws);
+  if (rc_) return rc_;
+  TL(r.l, ian_layer_backward_weight(r.l, x, dy, t->n, g.data(), (int)g.size(), t->touched.count(r.pnames[0]) ? 1 : 0, ws));
   for (auto& p : r.pnames) t->touched.insert(p);
   return 0;
 }
@@ -868,6 +906,10 @@ int ian_trainer_finalize(ian_trainer* t) {
   t->xin = dalloc(t, (size_t)t->n * 3 * 4096); t->zin = dalloc(t, (size_t)t->n * 100); t->epsin = dalloc(t, (size_t)t->n * 100);
   for (float* p : t->allocs)
     if (!p) return tfail(t, -20, "out of device memory");
+  if (hipStreamCreateWithFlags(&t->st2, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    t->st2 = nullptr;   // no second stream: weight gradients stay on the compute stream
+  }
   t->dirty = {"enc", "Z", "dec"};
   t->host.clear();
   t->finalized = true;
@@ -897,6 +939,7 @@ int ian_train_step(ian_trainer* t, int32_t which, const float* x, const float* z
   if (metrics9 && (rc = metrics(t, metrics9))) return rc;
   const bool gen = which == 0;
   if ((rc = backward(t, gen))) return rc;
+  if ((rc = join_side_stream(t))) return rc;
   if ((rc = regularizers(t, gen))) return rc;
   if ((rc = adam(t, gen ? t->dec : t->enc, gen ? "dec" : "enc"))) return rc;
   return adam(t, t->zp, "Z");
@@ -948,6 +991,7 @@ int ian_trainer_set_option(ian_trainer* t, const char* key, double value) {
   const std::string k = key;
   if (k == "learning_rate") t->cfg.learning_rate = value;  // train_IAN.py:523-527 learning-rate schedule
   else if (k == "head6") t->head6 = value != 0.0;
+  else if (k == "overlap_wgrad") t->overlap_wgrad = value != 0.0;
   else if (k == "update_running") t->update_running = value != 0.0;
   else return tfail(t, -1, "unknown option '%s'", key);
   return 0;
@@ -963,6 +1007,9 @@ const char* ian_trainer_last_error(ian_trainer* t) { return t ? t->err.c_str() :
 void ian_trainer_destroy(ian_trainer* t) {
   if (!t) return;
   IAN_GUARD_CHECK("ian_trainer_destroy");
+  (void)hipDeviceSynchronize();
+  for (hipEvent_t e : t->events) (void)hipEventDestroy(e);
+  if (t->st2) (void)hipStreamDestroy(t->st2);
   for (auto& kv : t->layers) ian_layer_destroy(kv.second.l);
   for (float* p : t->allocs)
     if (p) (void)hipFree(p);
