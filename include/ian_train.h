@@ -102,6 +102,16 @@ int ian_k_tree_sum(const float* partial, int32_t count, int32_t width, float* ou
 /* batch statistics -> mean, inv_std = 1/sqrt(var+eps), scale = gamma*inv_std, shift = beta - mean*scale */
 int ian_k_bn_make_affine(const float* sums, float count, float eps, const float* gamma, const float* beta, int32_t C,
                          float* mean, float* inv_std, float* scale, float* shift, void* stream);
+/* Single-process forms of the two-stage statistics above (no collective between the stages): the same chunk sums and the same
+   tree, finished in ONE launch.  Bit-identical to ian_k_colstats + ian_k_bn_make_affine (+ the running-average updates
+   r = keep*r + alpha*batch of lasagne BatchNormLayer, alpha = 0.1; run_mean/run_inv_std NULL: none), resp. to
+   ian_k_colstats(mode 1) + the two gradient accumulations dbeta (+)= s1, dgamma (+)= s2 (gbeta/ggamma NULL: none). */
+int ian_k_bn_stats_affine(const float* y, int64_t rows, int32_t C, int32_t stride, float* workspace, int32_t nchunks, float* sums,
+                          float count, float eps, const float* gamma, const float* beta, float* mean, float* inv_std, float* scale,
+                          float* shift, float* run_mean, float* run_inv_std, float keep, float alpha, void* stream);
+int ian_k_bn_bwd_stats(const float* dA, const float* a, const float* y, const float* mean, const float* inv_std, int64_t rows, int32_t C,
+                       int32_t stride, int32_t act, float* workspace, int32_t nchunks, float* sums, float* gbeta, int32_t acc_beta,
+                       float* ggamma, int32_t acc_gamma, void* stream);
 /* y = act(x*scale + shift) per channel (scale/shift may be NULL) */
 int ian_k_affine(const float* x, float* y, const float* scale, const float* shift, int64_t rows, int32_t C, int32_t stride,
                  int32_t act, void* stream);

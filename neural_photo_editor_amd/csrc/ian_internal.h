@@ -330,6 +330,12 @@ struct ColStatsArgs {
   int C, stride, mode, act;
 };
 hipError_t launch_colstats(const ColStatsArgs& a, int nchunks, float* sums, hipStream_t s);
+// single-process batch-norm statistics, second stage fused (kernels_train.hip: bn_finish_kernel / bn_bwd_finish_kernel)
+hipError_t launch_bn_stats_affine(const ColStatsArgs& a, int nchunks, float* sums, float count, float eps, const float* gamma,
+                                  const float* beta, float* mean, float* inv_std, float* scale, float* shift, float* run_mean,
+                                  float* run_inv_std, float keep, float alpha, hipStream_t s);
+hipError_t launch_bn_bwd_stats(const ColStatsArgs& a, int nchunks, float* sums, float* gbeta, int acc_beta, float* ggamma,
+                               int acc_gamma, hipStream_t s);
 // out[i] = pairwise tree over k < count of partial[k*width + i] (fixed order: see kernels_train.hip)
 hipError_t launch_tree_sum(const float* partial, int count, int width, float* out, hipStream_t s);
 hipError_t launch_bn_make_affine(const float* sums, float count, float eps, const float* gamma, const float* beta,

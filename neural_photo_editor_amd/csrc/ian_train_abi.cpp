@@ -52,6 +52,34 @@ int ian_k_bn_make_affine(const float* sums, float count, float eps, const float*
   return chk(launch_bn_make_affine(sums, count, eps, gamma, beta, C, mean, inv_std, scale, shift, ST), "ian_k_bn_make_affine");
 }
 
+int ian_k_bn_stats_affine(const float* y, int64_t rows, int32_t C, int32_t stride, float* workspace, int32_t nchunks, float* sums,
+                          float count, float eps, const float* gamma, const float* beta, float* mean, float* inv_std, float* scale,
+                          float* shift, float* run_mean, float* run_inv_std, float keep, float alpha, void* stream) {
+  if (!y || !workspace || !sums || !gamma || !beta || !mean || !inv_std || !scale || !shift || rows <= 0 || C <= 0 || (C & 3) ||
+      nchunks <= 0 || count <= 0 || (!run_mean) != (!run_inv_std))
+    return bad("ian_k_bn_stats_affine");
+  ColStatsArgs s;
+  s.x = y; s.a = nullptr; s.y = nullptr; s.mean = nullptr; s.inv_std = nullptr; s.partial = workspace; s.rows = rows; s.C = C;
+  s.stride = stride; s.mode = 0; s.act = 0;
+  if (nchunks > rows) nchunks = (int32_t)rows;
+  return chk(launch_bn_stats_affine(s, nchunks, sums, count, eps, gamma, beta, mean, inv_std, scale, shift, run_mean, run_inv_std, keep,
+                                    alpha, ST),
+             "ian_k_bn_stats_affine");
+}
+
+int ian_k_bn_bwd_stats(const float* dA, const float* a, const float* y, const float* mean, const float* inv_std, int64_t rows, int32_t C,
+                       int32_t stride, int32_t act, float* workspace, int32_t nchunks, float* sums, float* gbeta, int32_t acc_beta,
+                       float* ggamma, int32_t acc_gamma, void* stream) {
+  if (!dA || !y || !mean || !inv_std || !workspace || !sums || rows <= 0 || C <= 0 || (C & 3) || nchunks <= 0 || (!gbeta) != (!ggamma))
+    return bad("ian_k_bn_bwd_stats");
+  if (act != IAN_ACT_NONE && !a) return bad("ian_k_bn_bwd_stats (activation output missing)");
+  ColStatsArgs s;
+  s.x = dA; s.a = a; s.y = y; s.mean = mean; s.inv_std = inv_std; s.partial = workspace; s.rows = rows; s.C = C;
+  s.stride = stride; s.mode = 1; s.act = act;
+  if (nchunks > rows) nchunks = (int32_t)rows;
+  return chk(launch_bn_bwd_stats(s, nchunks, sums, gbeta, acc_beta, ggamma, acc_gamma, ST), "ian_k_bn_bwd_stats");
+}
+
 int ian_k_affine(const float* x, float* y, const float* scale, const float* shift, int64_t rows, int32_t C, int32_t stride,
                  int32_t act, void* stream) {
   if (!x || !y || rows <= 0 || C <= 0 || (C & 3)) return bad("ian_k_affine");

@@ -388,18 +388,15 @@ int bn_forward(ian_trainer* t, BN& bn, const float* y, float* a, int64_t rows, i
   float* ws;
   int rc;
   if ((rc = ws_for(t, rows, C, &ws))) return rc;
-  TK(ian_k_colstats(0, y, nullptr, nullptr, nullptr, nullptr, rows, C, stride, 0, ws, chunks(t, rows), bn.sums, t->st));
   bn.count = (float)count_rows;
-  TK(ian_k_bn_make_affine(bn.sums, bn.count, BN_EPS, gamma, beta, C, bn.mean, bn.inv_std, bn.scale, bn.shift, t->st));
-  TK(ian_k_affine(y, a, bn.scale, bn.shift, rows, C, stride, act, t->st));
+  float *rm = nullptr, *ri = nullptr;
   if (running && t->update_running) {  // r = (1 - alpha) r + alpha * batch   (Lasagne BatchNormLayer alpha = 0.1)
-    const std::pair<const char*, const float*> parts[2] = {{".mean", bn.mean}, {".inv_std", bn.inv_std}};
-    for (auto& pr : parts) {
-      float* r = P(t, std::string(running) + pr.first);
-      TK(ian_k_axpy(0.9f, r, r, C, 0, t->st));
-      TK(ian_k_axpy(0.1f, pr.second, r, C, 1, t->st));
-    }
+    rm = P(t, std::string(running) + ".mean");
+    ri = P(t, std::string(running) + ".inv_std");
   }
+  TK(ian_k_bn_stats_affine(y, rows, C, stride, ws, chunks(t, rows), bn.sums, bn.count, BN_EPS, gamma, beta, bn.mean, bn.inv_std, bn.scale,
+                           bn.shift, rm, ri, 0.9f, 0.1f, t->st));
+  TK(ian_k_affine(y, a, bn.scale, bn.shift, rows, C, stride, act, t->st));
   return 0;
 }
 int bn_backward(ian_trainer* t, BN& bn, const float* dA, const float* a, const float* y, float* dy, int64_t rows, int C, int stride, int act,
@@ -407,11 +404,14 @@ int bn_backward(ian_trainer* t, BN& bn, const float* dA, const float* a, const f
   float* ws;
   int rc;
   if ((rc = ws_for(t, rows, C, &ws))) return rc;
-  TK(ian_k_colstats(1, dA, a, y, bn.mean, bn.inv_std, rows, C, stride, act, ws, chunks(t, rows), bn.bsums, t->st));
+  float *gb = nullptr, *gg = nullptr;
+  int ab = 0, ag = 0;
   if (want_w) {
-    if ((rc = acc(t, bname, bn.bsums, C))) return rc;
-    if ((rc = acc(t, gname, bn.bsums + C, C))) return rc;
+    gb = G(t, bname); gg = G(t, gname);
+    ab = t->touched.count(bname) ? 1 : 0; ag = t->touched.count(gname) ? 1 : 0;
+    t->touched.insert(bname); t->touched.insert(gname);
   }
+  TK(ian_k_bn_bwd_stats(dA, a, y, bn.mean, bn.inv_std, rows, C, stride, act, ws, chunks(t, rows), bn.bsums, gb, ab, gg, ag, t->st));
   TK(ian_k_bn_bwd(dA, a, y, bn.mean, bn.inv_std, bn.scale, bn.bsums, bn.count, dy, rows, C, stride, act, t->st));
   return 0;
 }

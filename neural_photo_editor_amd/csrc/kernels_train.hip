@@ -43,63 +43,90 @@ static inline int grid_for(long long total, int cap = 8192) {
 //   mode 0: s1 = sum x,  s2 = sum x^2                          (batch-norm forward statistics)
 //   mode 1: g = dA*act'(a): s1 = sum g, s2 = sum g*xhat, xhat = (y-mean)*inv_std   (batch-norm backward: dbeta, dgamma)
 //   mode 2: g = dA*act'(a): s1 = sum g                        (bias gradient)
-// block = 64 channel quads x 4 row lanes; grid = (row chunks, ceil(C/256)).
+// grid = (row chunks, column groups); block shape below.
 //
 // Summation order is a function of the ROW INDEX only, not of how many rows there are: the caller cuts the rows
 // into equal chunks whose size depends on the per-image extent alone (trainer.py: one image or a fixed fraction
-// of one), a chunk is summed by 4 row lanes in a fixed order, and the chunk partials are combined by tree_sum,
+// of one), a chunk is summed by the block's row lanes in a fixed order, and the chunk partials are combined by tree_sum,
 // a pairwise (binary-counter) tree over the chunk index.  For power-of-two chunk counts
 //     tree(chunks of the whole minibatch) == tree(rank 0's chunks) + tree(rank 1's chunks)   bit for bit,
 // so the data-parallel step (per-rank tree, all-gather, tree over ranks in rank order) computes the SAME float32
 // batch statistics as the single-process step on the whole minibatch (SyncBN).
 // ------------------------------------------------------------------------------------------------
+// Block = CL float4 column lanes x (256 / CL) row lanes.  CL = 8 (32 channels = one 128-byte line per row, 32 row lanes) for
+// chunks of >= 64 rows: a 512-row chunk of a 128-channel map is then 4 workgroups instead of one half-idle one, and every
+// thread keeps 4 rows (x up to 3 tensors) of loads in flight; CL = 64 (the whole row across the block) for short chunks.
+// The order inside a chunk -- 4 interleaved accumulators per thread, (0+1)+(2+3), then a halving tree over the row lanes --
+// is fixed by the chunk's row count alone, so the chunk-count independence stated above is unchanged.
+template <int MODE, int CL>
 __global__ __launch_bounds__(256) void colstats_kernel(ColStatsArgs a) {
+  constexpr int RL = 256 / CL;
   __shared__ float4 red[2][256];
-  const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.y * 256 + q * 4;
+  const int q = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const int c = blockIdx.y * (CL * 4) + q * 4;
   const long long rows_per = (a.rows + gridDim.x - 1) / gridDim.x;
   const long long r0 = (long long)blockIdx.x * rows_per, r1 = min(a.rows, r0 + rows_per);
-  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-  if (c < a.C) {
-    float4 mean = s1, istd = s1;
-    if (a.mode == 1) {
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 s1[4] = {zero, zero, zero, zero}, s2[4] = {zero, zero, zero, zero};
+  if (c < a.C && r0 < r1) {
+    float4 mean = zero, istd = zero;
+    if (MODE == 1) {
       mean = *reinterpret_cast<const float4*>(a.mean + c);
       istd = *reinterpret_cast<const float4*>(a.inv_std + c);
     }
-    for (long long r = r0 + rl; r < r1; r += 4) {
-      const size_t off = (size_t)r * a.stride + c;
-      float4 x = *reinterpret_cast<const float4*>(a.x + off);
-      if (a.mode == 0) {
-        s1.x += x.x; s1.y += x.y; s1.z += x.z; s1.w += x.w;
-        s2.x += x.x * x.x; s2.y += x.y * x.y; s2.z += x.z * x.z; s2.w += x.w * x.w;
-      } else {
-        if (a.act) {
-          const float4 av = *reinterpret_cast<const float4*>(a.a + off);
-          x.x *= t_dact(av.x, a.act); x.y *= t_dact(av.y, a.act); x.z *= t_dact(av.z, a.act); x.w *= t_dact(av.w, a.act);
+    for (long long r = r0 + rl; r < r1; r += 4 * RL) {
+      float4 x[4], av[4], y[4];
+      bool ok[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {   // rows past the chunk are clamped (loads stay branch-free) and masked below
+        const long long rr = r + (long long)j * RL;
+        ok[j] = rr < r1;
+        const size_t off = (size_t)(ok[j] ? rr : r1 - 1) * a.stride + c;
+        x[j] = *reinterpret_cast<const float4*>(a.x + off);
+        if (MODE != 0 && a.act) av[j] = *reinterpret_cast<const float4*>(a.a + off);
+        if (MODE == 1) y[j] = *reinterpret_cast<const float4*>(a.y + off);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float4 v = x[j];
+        if (MODE != 0 && a.act) {
+          v.x *= t_dact(av[j].x, a.act); v.y *= t_dact(av[j].y, a.act); v.z *= t_dact(av[j].z, a.act); v.w *= t_dact(av[j].w, a.act);
         }
-        s1.x += x.x; s1.y += x.y; s1.z += x.z; s1.w += x.w;
-        if (a.mode == 1) {
-          const float4 y = *reinterpret_cast<const float4*>(a.y + off);
-          s2.x += x.x * (y.x - mean.x) * istd.x; s2.y += x.y * (y.y - mean.y) * istd.y;
-          s2.z += x.z * (y.z - mean.z) * istd.z; s2.w += x.w * (y.w - mean.w) * istd.w;
+        if (!ok[j]) v = zero;
+        s1[j].x += v.x; s1[j].y += v.y; s1[j].z += v.z; s1[j].w += v.w;
+        if (MODE == 0) {
+          s2[j].x += v.x * v.x; s2[j].y += v.y * v.y; s2[j].z += v.z * v.z; s2[j].w += v.w * v.w;
+        } else if (MODE == 1) {
+          s2[j].x += v.x * (y[j].x - mean.x) * istd.x; s2[j].y += v.y * (y[j].y - mean.y) * istd.y;
+          s2[j].z += v.z * (y[j].z - mean.z) * istd.z; s2[j].w += v.w * (y[j].w - mean.w) * istd.w;
         }
       }
     }
   }
-  red[0][threadIdx.x] = s1;
-  red[1][threadIdx.x] = s2;
+  float4 t1, t2;
+  t1.x = (s1[0].x + s1[1].x) + (s1[2].x + s1[3].x); t1.y = (s1[0].y + s1[1].y) + (s1[2].y + s1[3].y);
+  t1.z = (s1[0].z + s1[1].z) + (s1[2].z + s1[3].z); t1.w = (s1[0].w + s1[1].w) + (s1[2].w + s1[3].w);
+  t2.x = (s2[0].x + s2[1].x) + (s2[2].x + s2[3].x); t2.y = (s2[0].y + s2[1].y) + (s2[2].y + s2[3].y);
+  t2.z = (s2[0].z + s2[1].z) + (s2[2].z + s2[3].z); t2.w = (s2[0].w + s2[1].w) + (s2[2].w + s2[3].w);
+  red[0][threadIdx.x] = t1;
+  red[1][threadIdx.x] = t2;
   __syncthreads();
+#pragma unroll
+  for (int w = RL / 2; w >= 1; w >>= 1) {   // halving tree over the row lanes: lane l takes l + w
+    if (rl < w) {
+      const float4 u = red[0][threadIdx.x + w * CL], v = red[1][threadIdx.x + w * CL];
+      float4 m = red[0][threadIdx.x], n = red[1][threadIdx.x];
+      m.x += u.x; m.y += u.y; m.z += u.z; m.w += u.w;
+      n.x += v.x; n.y += v.y; n.z += v.z; n.w += v.w;
+      red[0][threadIdx.x] = m;
+      red[1][threadIdx.x] = n;
+    }
+    __syncthreads();
+  }
   if (rl == 0 && c < a.C) {
-    // (lane0 + lane1) + (lane2 + lane3): fixed, and independent of the number of chunks
-    const float4 u1 = red[0][q + 64], u2 = red[0][q + 128], u3 = red[0][q + 192];
-    const float4 v1 = red[1][q + 64], v2 = red[1][q + 128], v3 = red[1][q + 192];
-    s1.x = (s1.x + u1.x) + (u2.x + u3.x); s1.y = (s1.y + u1.y) + (u2.y + u3.y);
-    s1.z = (s1.z + u1.z) + (u2.z + u3.z); s1.w = (s1.w + u1.w) + (u2.w + u3.w);
-    s2.x = (s2.x + v1.x) + (v2.x + v3.x); s2.y = (s2.y + v1.y) + (v2.y + v3.y);
-    s2.z = (s2.z + v1.z) + (v2.z + v3.z); s2.w = (s2.w + v1.w) + (v2.w + v3.w);
     float* p = a.partial + (size_t)blockIdx.x * 2 * a.C;
-    *reinterpret_cast<float4*>(p + c) = s1;
-    *reinterpret_cast<float4*>(p + a.C + c) = s2;
+    *reinterpret_cast<float4*>(p + c) = red[0][threadIdx.x];
+    *reinterpret_cast<float4*>(p + a.C + c) = red[1][threadIdx.x];
   }
 }
 
@@ -133,15 +160,14 @@ __device__ __forceinline__ float tree_sum_seq(const float* __restrict__ p, size_
 }
 // out[i] = tree over k of partial[k*width + i].  Block = 16 columns x 16 lanes; for a power-of-two count each lane
 // takes a contiguous 1/16th (its own subtree) and the lanes meet pairwise in LDS, which is the same tree.
-__global__ __launch_bounds__(256) void tree_sum_kernel(const float* __restrict__ partial, int count, int width,
-                                                       float* __restrict__ out) {
-  __shared__ float red[256];
-  const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
-  const int i = blockIdx.x * 16 + col;
+// tree_column: every thread of the block calls it; the column's total is in red[col] afterwards.
+__device__ __forceinline__ void tree_column(const float* __restrict__ partial, int count, int width, int i, bool valid,
+                                            float* red) {
+  const int lane = threadIdx.x >> 4;
   const bool pow2 = (count & (count - 1)) == 0;
   const int L = pow2 ? min(16, count) : 1;   // lanes in use
   float s = 0.f;
-  if (i < width && lane < L) {
+  if (valid && lane < L) {
     const int per = count / L;
     s = tree_sum_seq(partial + (size_t)lane * per * width + i, (size_t)width, per);
   }
@@ -151,6 +177,13 @@ __global__ __launch_bounds__(256) void tree_sum_kernel(const float* __restrict__
     if (lane % (2 * w) == 0 && lane + w < L) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 16 * w];
     __syncthreads();
   }
+}
+__global__ __launch_bounds__(256) void tree_sum_kernel(const float* __restrict__ partial, int count, int width,
+                                                       float* __restrict__ out) {
+  __shared__ float red[256];
+  const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + col;
+  tree_column(partial, count, width, i, i < width, red);
   if (lane == 0 && i < width) out[i] = red[col];
 }
 hipError_t launch_tree_sum(const float* partial, int count, int width, float* out, hipStream_t s) {
@@ -158,9 +191,121 @@ hipError_t launch_tree_sum(const float* partial, int count, int width, float* ou
   hipLaunchKernelGGL(tree_sum_kernel, dim3((width + 15) / 16), dim3(256), 0, s, partial, count, width, out);
   return hipGetLastError();
 }
+
+// batch statistics -> folded affine (App. B.3): mean, biased variance, inv_std = 1/sqrt(var+eps).  One statement of the
+// arithmetic, contraction off, for bn_make_affine_kernel and bn_finish_kernel: the fused single-process statistics and the
+// two-stage data-parallel ones (all-gather between the tree and this) must agree bit for bit.
+__device__ __forceinline__ void bn_affine_math(float s1, float s2, float count, float eps, float gamma, float beta,
+                                               float& m, float& is, float& sc, float& sh) {
+#pragma clang fp contract(off)
+  m = s1 / count;
+  float var = s2 / count - m * m;
+  var = var > 0.f ? var : 0.f;
+  is = 1.f / sqrtf(var + eps);
+  sc = gamma * is;
+  sh = beta - m * sc;
+}
+// r = keep * r + alpha * batch, rounded as the two ian_k_axpy launches it replaces round it (product, then fused add)
+__device__ __forceinline__ float running_math(float r, float batch, float keep, float alpha) {
+#pragma clang fp contract(off)
+  const float kept = keep * r;
+  return __builtin_fmaf(alpha, batch, kept);
+}
+
+// second stage of the batch-norm FORWARD statistics in one launch (single-process step): the tree of tree_sum_kernel over
+// columns c and C + c of partial[chunk][2][C], bn_make_affine's arithmetic, and the running averages of the pass that owns
+// them.  Block = 8 channels x {s1, s2} x 16 lanes.
+struct BnFinishArgs {
+  const float* partial;
+  const float* gamma;
+  const float* beta;
+  float* sums;
+  float* mean;
+  float* inv_std;
+  float* scale;
+  float* shift;
+  float* run_mean;     // or nullptr
+  float* run_inv_std;
+  float n, eps, keep, alpha;
+  int count, C;
+};
+__global__ __launch_bounds__(256) void bn_finish_kernel(BnFinishArgs a) {
+  __shared__ float red[256];
+  const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 8 + (col & 7);
+  tree_column(a.partial, a.count, 2 * a.C, (col >> 3) * a.C + ch, ch < a.C, red);
+  if (lane == 0 && col < 8 && ch < a.C) {
+    const float s1 = red[col], s2 = red[col + 8];
+    a.sums[ch] = s1;
+    a.sums[a.C + ch] = s2;
+    float m, is, sc, sh;
+    bn_affine_math(s1, s2, a.n, a.eps, a.gamma[ch], a.beta[ch], m, is, sc, sh);
+    a.mean[ch] = m;
+    a.inv_std[ch] = is;
+    a.scale[ch] = sc;
+    a.shift[ch] = sh;
+    if (a.run_mean) {
+      a.run_mean[ch] = running_math(a.run_mean[ch], m, a.keep, a.alpha);
+      a.run_inv_std[ch] = running_math(a.run_inv_std[ch], is, a.keep, a.alpha);
+    }
+  }
+}
+// second stage of the batch-norm BACKWARD statistics: the tree, then dbeta (+)= s1 and dgamma (+)= s2 (the two gradient
+// accumulations that used to be ian_k_axpy launches)
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restrict__ partial, int count, int C,
+                                                            float* __restrict__ sums, float* __restrict__ gbeta, int acc_beta,
+                                                            float* __restrict__ ggamma, int acc_gamma) {
+  __shared__ float red[256];
+  const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + col;
+  tree_column(partial, count, 2 * C, i, i < 2 * C, red);
+  if (lane == 0 && i < 2 * C) {
+    const float v = red[col];
+    sums[i] = v;
+    if (gbeta) {
+      if (i < C) gbeta[i] = (acc_beta ? gbeta[i] : 0.f) + v;
+      else ggamma[i - C] = (acc_gamma ? ggamma[i - C] : 0.f) + v;
+    }
+  }
+}
+static void launch_colstats_stage1(const ColStatsArgs& a, int nchunks, hipStream_t s);
+hipError_t launch_bn_stats_affine(const ColStatsArgs& a, int nchunks, float* sums, float count, float eps, const float* gamma,
+                                  const float* beta, float* mean, float* inv_std, float* scale, float* shift, float* run_mean,
+                                  float* run_inv_std, float keep, float alpha, hipStream_t s) {
+  if ((a.C & 3) || a.mode != 0 || nchunks <= 0 || nchunks >= (1 << TS_LEVELS)) return hipErrorInvalidValue;
+  launch_colstats_stage1(a, nchunks, s);
+  BnFinishArgs f;
+  f.partial = a.partial; f.gamma = gamma; f.beta = beta; f.sums = sums; f.mean = mean; f.inv_std = inv_std; f.scale = scale;
+  f.shift = shift; f.run_mean = run_mean; f.run_inv_std = run_inv_std; f.n = count; f.eps = eps; f.keep = keep; f.alpha = alpha;
+  f.count = nchunks; f.C = a.C;
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((a.C + 7) / 8), dim3(256), 0, s, f);
+  return hipGetLastError();
+}
+hipError_t launch_bn_bwd_stats(const ColStatsArgs& a, int nchunks, float* sums, float* gbeta, int acc_beta, float* ggamma,
+                               int acc_gamma, hipStream_t s) {
+  if ((a.C & 3) || a.mode != 1 || nchunks <= 0 || nchunks >= (1 << TS_LEVELS)) return hipErrorInvalidValue;
+  launch_colstats_stage1(a, nchunks, s);
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((2 * a.C + 15) / 16), dim3(256), 0, s, a.partial, nchunks, a.C, sums, gbeta,
+                     acc_beta, ggamma, acc_gamma);
+  return hipGetLastError();
+}
+static void launch_colstats_stage1(const ColStatsArgs& a, int nchunks, hipStream_t s) {
+  const long long rows_per = (a.rows + nchunks - 1) / nchunks;
+  const bool narrow = rows_per >= 64;
+  const dim3 grid(nchunks, narrow ? (a.C + 31) / 32 : (a.C + 255) / 256);
+#define IAN_COLSTATS(M)                                                                           \
+  do {                                                                                            \
+    if (narrow) hipLaunchKernelGGL((colstats_kernel<M, 8>), grid, dim3(256), 0, s, a);            \
+    else hipLaunchKernelGGL((colstats_kernel<M, 64>), grid, dim3(256), 0, s, a);                  \
+  } while (0)
+  if (a.mode == 0) IAN_COLSTATS(0);
+  else if (a.mode == 1) IAN_COLSTATS(1);
+  else IAN_COLSTATS(2);
+#undef IAN_COLSTATS
+}
 hipError_t launch_colstats(const ColStatsArgs& a, int nchunks, float* sums, hipStream_t s) {
   if (a.C & 3) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(colstats_kernel, dim3(nchunks, (a.C + 255) / 256), dim3(256), 0, s, a);
+  launch_colstats_stage1(a, nchunks, s);
   return launch_tree_sum(a.partial, nchunks, 2 * a.C, sums, s);
 }
 
@@ -172,15 +317,12 @@ __global__ __launch_bounds__(256) void bn_make_affine_kernel(const float* __rest
                                                              float* __restrict__ scale, float* __restrict__ shift) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  const float m = sums[c] / count;
-  float var = sums[C + c] / count - m * m;
-  var = var > 0.f ? var : 0.f;
-  const float is = 1.f / sqrtf(var + eps);
+  float m, is, sc, sh;
+  bn_affine_math(sums[c], sums[C + c], count, eps, gamma[c], beta[c], m, is, sc, sh);
   mean[c] = m;
   inv_std[c] = is;
-  const float sc = gamma[c] * is;
   scale[c] = sc;
-  shift[c] = beta[c] - m * sc;
+  shift[c] = sh;
 }
 hipError_t launch_bn_make_affine(const float* sums, float count, float eps, const float* gamma, const float* beta,
                                  int C, float* mean, float* inv_std, float* scale, float* shift, hipStream_t s) {

@@ -478,27 +478,43 @@ class Trainer:
         """batch statistics over this pass (all ranks when exact) -> a = act(bn(y)).  ``running``: name of the
         BatchNormLayer whose running averages this pass updates (the pass that sees the real minibatch)."""
         k = self.k
+        upd = running is not None and self.update_running
+        rm = self.stats.view(self.stats.p, running + ".mean") if upd else None
+        ri = self.stats.view(self.stats.p, running + ".inv_std") if upd else None
+        if not self.exact:                               # no collective between the two stages: one fused second stage
+            bn.count = float(count_rows)
+            k.bn_stats_affine(y, rows, C, stride, self._ws(rows, C), self._chunks(rows), bn.sums, bn.count, BN_EPS, gamma, beta,
+                              bn.mean, bn.inv_std, bn.scale, bn.shift, rm, ri, 1.0 - self.bn_alpha, self.bn_alpha)
+            k.affine(y, a, bn.scale, bn.shift, rows, C, stride, act)
+            return
         k.colstats(0, y, None, None, None, None, rows, C, stride, 0, self._ws(rows, C), self._chunks(rows), bn.sums)
-        if self.exact:
-            self.comm.all_reduce_sum_ordered(bn.sums, k)
-        bn.count = float(count_rows * (self.comm.world if self.exact else 1))
+        self.comm.all_reduce_sum_ordered(bn.sums, k)
+        bn.count = float(count_rows * self.comm.world)
         k.bn_make_affine(bn.sums, bn.count, BN_EPS, gamma, beta, C, bn.mean, bn.inv_std, bn.scale, bn.shift)
         k.affine(y, a, bn.scale, bn.shift, rows, C, stride, act)
-        if running is not None and self.update_running:
-            for t, cur in ((".mean", bn.mean), (".inv_std", bn.inv_std)):     # r = (1-alpha) r + alpha * batch
-                r = self.stats.view(self.stats.p, running + t)
+        if upd:
+            for r, cur in ((rm, bn.mean), (ri, bn.inv_std)):                  # r = (1-alpha) r + alpha * batch
                 k.axpy(1.0 - self.bn_alpha, r, r, C, 0)
                 k.axpy(self.bn_alpha, cur, r, C, 1)
 
     def _bn_backward(self, bn, dA, a, y, dy, rows, C, stride, act, gname, bname, want_w):
         k = self.k
+        if not self.exact:
+            gb = self.G(bname) if want_w else None
+            gg = self.G(gname) if want_w else None
+            ab, ag = int(bname in self.touched), int(gname in self.touched)
+            k.bn_bwd_stats(dA, a, y, bn.mean, bn.inv_std, rows, C, stride, act, self._ws(rows, C), self._chunks(rows), bn.bsums,
+                           gb, ab, gg, ag)
+            if want_w:
+                self.touched.update((bname, gname))
+            k.bn_bwd(dA, a, y, bn.mean, bn.inv_std, bn.scale, bn.bsums, bn.count, dy, rows, C, stride, act)
+            return
         k.colstats(1, dA, a, y, bn.mean, bn.inv_std, rows, C, stride, act, self._ws(rows, C), self._chunks(rows), bn.bsums)
-        if self.exact:
-            self.comm.all_reduce_sum_ordered(bn.bsums, k)
+        self.comm.all_reduce_sum_ordered(bn.bsums, k)
         if want_w:
             # with exact statistics every rank already holds the GLOBAL dbeta/dgamma: pre-divide so that the
             # gradient all-reduce (a sum over ranks) restores them
-            sc = 1.0 / self.comm.world if self.exact else 1.0
+            sc = 1.0 / self.comm.world
             self._acc(bname, bn.bsums[:C], sc)
             self._acc(gname, bn.bsums[C:], sc)
         k.bn_bwd(dA, a, y, bn.mean, bn.inv_std, bn.scale, bn.bsums, bn.count, dy, rows, C, stride, act)

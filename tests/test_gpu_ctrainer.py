@@ -79,8 +79,8 @@ def test_c_step_from_host_buffers_only():
     ct.close()                                                                  # guard bands are verified here in the sanitized build
 
 
-@pytest.mark.parametrize("which", ["gen", "discrim"])
-def test_weight_gradient_stream_is_bitwise_the_single_stream_step(which):
+@pytest.mark.parametrize("which,B", [("gen", 4), ("discrim", 4), ("gen", 32)])
+def test_weight_gradient_stream_is_bitwise_the_single_stream_step(which, B):
     """overlap_wgrad=1 (default) issues every weight-gradient GEMM on a second stream, joined before the regularizers.  The
     COLD first step is the sharp case: each layer builds its split-K schedule and zeroes its partial buffer on first use, and that
     zeroing must have landed before the second stream's GEMM writes the same buffer."""

@@ -149,6 +149,60 @@ def test_dense_layers(env, fin, fout, flat, unflat):
     layer.close()
 
 
+@pytest.mark.parametrize("rows,nchunks,C,act", [(4 * 1024, 8, 128, 2), (2 * 256, 2, 256, 1), (3 * 100, 3, 36, 2), (4 * 16, 64, 32, 0),
+                                                (128, 128, 2048, 1)])
+def test_fused_statistics_are_bitwise_the_two_stage_ones(env, rows, nchunks, C, act):
+    """ian_k_bn_stats_affine / ian_k_bn_bwd_stats (one launch for the second stage, used by the single-process step) against
+    ian_k_colstats + ian_k_bn_make_affine + the ian_k_axpy running-average / gradient accumulations (the data-parallel step):
+    bit for bit, on chunks long enough for the 32-row-lane block shape (>= 64 rows per chunk), with a ragged tail (100 rows per
+    chunk) and on the short-chunk shape; the sums themselves against float64."""
+    lib, T, k = env
+    rs = np.random.RandomState(rows + C)
+    stride = cs(C)
+    dev = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda()
+    pad = lambda v: dev(np.pad(v, ((0, 0), (0, stride - C))))
+    y, dA = (rs.randn(rows, C) * 2 + 0.5).astype(np.float32), rs.randn(rows, C).astype(np.float32)
+    gamma, beta = dev(rs.uniform(0.5, 1.5, C)), dev(rs.randn(C))
+    run0 = rs.randn(2, C).astype(np.float32)
+    g0 = rs.randn(2, C).astype(np.float32)
+    yd, dAd = pad(y), pad(dA)
+    ws = torch.zeros(nchunks * 2 * C, device="cuda")
+    out = {}
+    for fused in (False, True):
+        bn = T.BN(torch, C, "cuda")
+        rm, ri = dev(run0[0]), dev(run0[1])
+        gb, gg = dev(g0[0]), dev(g0[1])
+        ad, dyd = torch.zeros_like(yd), torch.zeros_like(yd)
+        if fused:
+            k.bn_stats_affine(yd, rows, C, stride, ws, nchunks, bn.sums, float(rows), 1e-4, gamma, beta, bn.mean, bn.inv_std, bn.scale,
+                              bn.shift, rm, ri, 1.0 - 0.1, 0.1)
+        else:
+            k.colstats(0, yd, None, None, None, None, rows, C, stride, 0, ws, nchunks, bn.sums)
+            k.bn_make_affine(bn.sums, float(rows), 1e-4, gamma, beta, C, bn.mean, bn.inv_std, bn.scale, bn.shift)
+            for r, cur in ((rm, bn.mean), (ri, bn.inv_std)):
+                k.axpy(1.0 - 0.1, r, r, C, 0)
+                k.axpy(0.1, cur, r, C, 1)
+        k.affine(yd, ad, bn.scale, bn.shift, rows, C, stride, act)
+        if fused:
+            k.bn_bwd_stats(dAd, ad, yd, bn.mean, bn.inv_std, rows, C, stride, act, ws, nchunks, bn.bsums, gb, 1, gg, 0)
+        else:
+            k.colstats(1, dAd, ad, yd, bn.mean, bn.inv_std, rows, C, stride, act, ws, nchunks, bn.bsums)
+            k.axpy(1.0, bn.bsums[:C], gb, C, 1)
+            k.axpy(1.0, bn.bsums[C:], gg, C, 0)
+        out[fused] = [v.cpu().numpy().copy() for v in (bn.sums, bn.mean, bn.inv_std, bn.scale, bn.shift, rm, ri, bn.bsums, gb, gg)]
+    for i, (u, f) in enumerate(zip(out[False], out[True])):
+        assert np.array_equal(u, f), i
+    sums, bsums = out[True][0], out[True][7]
+    y64 = y.astype(np.float64)
+    assert rel(sums[:C], y64.sum(0)) < 1e-5 and rel(sums[C:], (y64 ** 2).sum(0)) < 1e-5
+    mean, var = y64.mean(0), y64.var(0)
+    pre = (y64 - mean) / np.sqrt(var + 1e-4) * gamma.cpu().numpy() + beta.cpu().numpy()
+    dact = {0: np.ones_like(pre), 1: (pre > 0).astype(np.float64), 2: np.where(pre > 0, 1.0, 0.2)}[act]
+    g = dA * dact
+    assert rel(bsums[:C], g.sum(0)) < 1e-4 and rel(bsums[C:], (g * (y64 - mean) / np.sqrt(var + 1e-4)).sum(0)) < 1e-4
+    assert np.array_equal(out[True][8], g0[0] + bsums[:C]) and np.array_equal(out[True][9], bsums[C:])   # accumulate vs overwrite
+
+
 @pytest.mark.parametrize("rows,C,act", [(4 * 16, 32, 2), (3 * 64, 128, 2), (5, 1000, 1), (4, 100, 0)])
 def test_batchnorm_train_forward_backward(env, rows, C, act):
     lib, T, k = env
