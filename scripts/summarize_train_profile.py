@@ -18,6 +18,9 @@ for r in rows:
     a[0] += 1
     a[1] += d
 total = sum(v[1] for v in tot.values())
+by_stream = collections.OrderedDict()
+for r in rows:
+    by_stream[r.get("Stream_Id", "?")] = by_stream.get(r.get("Stream_Id", "?"), 0.0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 span = (int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / 1e6
 iters = sum(1 for r in rows if "adam_kernel" in r["Kernel_Name"]) // 4 or 1   # 4 parameter groups... per update: see below
 gemm = sum(v[1] for k, v in tot.items() if k.startswith("tapgemm_kernel") or k.startswith("tapwgrad_kernel"))
@@ -31,6 +34,11 @@ with open(out + ".md", "w") as f:
             "synthetic data, after the layer autotune and two warm-up updates (cut at the marker launch by\n"
             "scripts/summarize_train_profile.py).\n\n")
     f.write("Sum of kernel durations: **%.1f ms** for 4 updates (%.1f ms per update; first-to-last-kernel span %.1f ms).\n" % (total / 1e3, total / 4e3, span))
+    if total / 1e3 > 1.02 * span:
+        f.write("The sum exceeds the span because two streams run concurrently (`overlap_wgrad`: weight-gradient GEMMs + their split\n"
+                "reduces on the trainer's second stream, everything else on the compute stream); a kernel that shares the chip with a\n"
+                "GEMM of the other stream reports a longer duration than it has alone (e.g. `colstats`, `bn_bwd_finish`).  Per-stream\n"
+                "busy time: %s.\n" % ", ".join("stream %s %.1f ms" % (sid, ms / 1e3) for sid, ms in sorted(by_stream.items())))
     if train:
         f.write("bench.py `train_step` of the same commit: update_gen %.1f ms, update_discrim %.1f ms wall, %.0f images/s.\n"
                 % (train["update_gen_ms"], train["update_discrim_ms"], train["images_per_s"]))
