@@ -307,3 +307,25 @@ def test_host_class_has_the_reference_surface():
     npe = open(os.path.join(REF, "NPE.py")).read()
     used = set(re.findall(r"model\.(\w+)\(", npe))
     assert used <= set(ref_methods) and "imgradRGB" in used and "sample_at" in used
+
+
+def test_bench_quotes_pmc_traffic_only_for_the_sources_it_was_measured_on(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from a committed rocprofv3 summary (PMC counters cannot be read in-process): it may be
+    quoted only when the summary's csrc digest is the digest of the sources the running library was built from; otherwise the
+    field is null and the reason names both digests.  The committed round-3 summaries must match the committed sources."""
+    import json
+    import bench
+    from neural_photo_editor_amd import build
+    for arch, B, tag in (("IAN_simple", 64, "ian_simple_b64"), ("IAN", 256, "ian_b256")):
+        v, src = bench.pmc_traffic(arch, B)
+        assert v and v > 1e6 and src.startswith("profiles/r03_") and tag in src, (v, src)
+    assert bench.pmc_traffic("IAN_simple", 32) == (None, None)            # no committed profile for that workload
+    (tmp_path / "profiles").mkdir()
+    stale = {"tapgemm_traffic_bytes_per_launch": 1.0e8, "csrc_digest": "0" * 64}
+    (tmp_path / "profiles" / "r09_ian_simple_b64.json").write_text(json.dumps(stale))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    v, why = bench.pmc_traffic("IAN_simple", 64)
+    assert v is None and "stale" in why and build._digest()[:12] in why
+    stale["csrc_digest"] = build._digest()
+    (tmp_path / "profiles" / "r09_ian_simple_b64.json").write_text(json.dumps(stale))
+    assert bench.pmc_traffic("IAN_simple", 64) == (1.0e8, os.path.join("profiles", "r09_ian_simple_b64.json"))
