@@ -85,7 +85,9 @@ void ian_layer_destroy(ian_layer* l);
 
 /* ---- element-wise / reduction ops (names follow the reference construct they implement) ------------------- */
 const char* ian_k_last_error(void);
-/* per-channel sums over NHWC rows, two-stage: workspace >= nchunks*2*C floats, sums = [2][C].
+/* per-channel sums over NHWC rows, two-stage, in FLOAT64 (every float32 element is widened before it is squared / added; see
+   kernels_train.hip "NUMERICS": the variance E[x^2]-E[x]^2 formed from these sums is better conditioned than Lasagne's float32
+   two-pass input.var): workspace >= nchunks*2*C doubles, sums = double[2][C].
    mode 0: (sum x, sum x^2) of x.   mode 1: g = x*act'(a): (sum g, sum g*xhat), xhat=(y-mean)*inv_std.
    mode 2: g = x*act'(a): (sum g, -).                                   batch_norm / bias gradients (App. B.3)
    The rows are cut into nchunks equal chunks (rows % nchunks == 0 for the guarantee below), each summed in a fixed
@@ -93,33 +95,35 @@ const char* ian_k_last_error(void);
    chunk counts the result over a whole minibatch equals, bit for bit, the tree over ranks of per-rank results
    computed with the same chunk size: the data-parallel batch statistics are those of the single-process step. */
 int ian_k_colstats(int32_t mode, const float* x, const float* a, const float* y, const float* mean, const float* inv_std,
-                   int64_t rows, int32_t C, int32_t stride, int32_t act, float* workspace, int32_t nchunks, float* sums,
+                   int64_t rows, int32_t C, int32_t stride, int32_t act, double* workspace, int32_t nchunks, double* sums,
                    void* stream);
 /* out[i] = pairwise tree (T(lo,hi) = T(lo,lo+m) + T(lo+m,hi), m = largest power of two below hi-lo) over k < count
    of partial[k*width + i]: the second stage of ian_k_colstats, and the rank-ordered combine of all-gathered
    per-rank sums (SyncBN) */
-int ian_k_tree_sum(const float* partial, int32_t count, int32_t width, float* out, void* stream);
+int ian_k_tree_sum(const double* partial, int32_t count, int32_t width, double* out, void* stream);
 /* batch statistics -> mean, inv_std = 1/sqrt(var+eps), scale = gamma*inv_std, shift = beta - mean*scale */
-int ian_k_bn_make_affine(const float* sums, float count, float eps, const float* gamma, const float* beta, int32_t C,
+int ian_k_bn_make_affine(const double* sums, float count, float eps, const float* gamma, const float* beta, int32_t C,
                          float* mean, float* inv_std, float* scale, float* shift, void* stream);
 /* Single-process forms of the two-stage statistics above (no collective between the stages): the same chunk sums and the same
    tree, finished in ONE launch.  Bit-identical to ian_k_colstats + ian_k_bn_make_affine (+ the running-average updates
    r = keep*r + alpha*batch of lasagne BatchNormLayer, alpha = 0.1; run_mean/run_inv_std NULL: none), resp. to
    ian_k_colstats(mode 1) + the two gradient accumulations dbeta (+)= s1, dgamma (+)= s2 (gbeta/ggamma NULL: none). */
-int ian_k_bn_stats_affine(const float* y, int64_t rows, int32_t C, int32_t stride, float* workspace, int32_t nchunks, float* sums,
+int ian_k_bn_stats_affine(const float* y, int64_t rows, int32_t C, int32_t stride, double* workspace, int32_t nchunks, double* sums,
                           float count, float eps, const float* gamma, const float* beta, float* mean, float* inv_std, float* scale,
                           float* shift, float* run_mean, float* run_inv_std, float keep, float alpha, void* stream);
 int ian_k_bn_bwd_stats(const float* dA, const float* a, const float* y, const float* mean, const float* inv_std, int64_t rows, int32_t C,
-                       int32_t stride, int32_t act, float* workspace, int32_t nchunks, float* sums, float* gbeta, int32_t acc_beta,
+                       int32_t stride, int32_t act, double* workspace, int32_t nchunks, double* sums, float* gbeta, int32_t acc_beta,
                        float* ggamma, int32_t acc_gamma, void* stream);
 /* y = act(x*scale + shift) per channel (scale/shift may be NULL) */
 int ian_k_affine(const float* x, float* y, const float* scale, const float* shift, int64_t rows, int32_t C, int32_t stride,
                  int32_t act, void* stream);
 /* backward of [batch_norm ->] nonlinearity: dy = scale*(g - s1/N - xhat*s2/N), g = dA*act'(a); sums NULL: dy = g */
 int ian_k_bn_bwd(const float* dA, const float* a, const float* y, const float* mean, const float* inv_std,
-                 const float* scale, const float* sums, float count, float* dy, int64_t rows, int32_t C, int32_t stride,
+                 const float* scale, const double* sums, float count, float* dy, int64_t rows, int32_t C, int32_t stride,
                  int32_t act, void* stream);
 int ian_k_axpy(float alpha, const float* x, float* y, int64_t n, int32_t accumulate, void* stream);
+/* y (+)= (float)(alpha * x) for the float64 column sums of ian_k_colstats (bias / dbeta / dgamma gradients: rounded once) */
+int ian_k_axpy_f64(double alpha, const double* x, float* y, int64_t n, int32_t accumulate, void* stream);
 int ian_k_gather(const float* src, const int32_t* map, float* dst, int64_t count, void* stream);
 int ian_k_nchw_to_nhwc(const float* src, float* dst, int32_t n, int32_t hw, int32_t c, int32_t stride, void* stream);
 int ian_k_nhwc_to_nchw(const float* src, int32_t stride, float* dst, int32_t n, int32_t hw, int32_t c, void* stream);
@@ -175,8 +179,8 @@ int ian_k_adam(float* p, const float* g, float* m, float* v, int64_t n, float a_
  * ian_trainer owns the full IAN graph of IAN.py:67-228 in training mode: the three Adam groups of train_IAN.py:184-194
  * (encoder_params, Z_params, decoder_params; reference layouts and Theano names), every activation of the three passes of
  * train_IAN.py:116-149, the batch-norm running averages and the frozen MADE parameters.  csrc/ian_trainer.cpp wires it
- * from the entry points above and nothing else; one process, one GPU (the data-parallel step is sequenced by
- * neural_photo_editor_amd/trainer.py, which has torch.distributed / RCCL at hand). */
+ * from the entry points above and nothing else, and it is the ONLY sequencer of the step: one GPU, or one rank of a
+ * data-parallel job whose collectives arrive through ian_comm_ops (below). */
 typedef struct ian_trainer ian_trainer;
 typedef struct ian_train_config {
   int32_t batch;         /* images per update: batch statistics, the MinibatchLayer and the loss means are over exactly this many */
@@ -191,6 +195,29 @@ typedef struct ian_train_config {
   float recon_weight, feature_weight, dg_weight, dd_weight, agr_weight, ags_weight;   /* IAN.py:53-58 */
 } ian_train_config;
 int ian_trainer_create(const ian_train_config* cfg, ian_trainer** out);
+/* Data parallel (train_IAN.py has none; north_star: minibatch sharded over the GPUs of one node, RCCL gradient all-reduce
+   overlapped with backward).  One process per GPU; cfg.batch is the PER-RANK batch; every loss is a mean over the GLOBAL batch
+   so that summing per-rank gradients gives the 1-GPU gradient.  The host supplies the collectives on DEVICE buffers and HIP
+   streams -- neural_photo_editor_amd/trainer.py fills the table from torch.distributed (backend "nccl" = RCCL over xGMI; gloo
+   in the tests); a C caller would fill it from librccl (ncclAllReduce / ncclAllGather on the given stream):
+     allreduce_sum  buf[0..count) <- sum over ranks, in place.  Ordered after everything enqueued on `stream` at the time of the
+                    call; may complete asynchronously (the trainer calls it on its own side stream while backward goes on).
+     wait_all       make `stream` wait (device side where the backend can, else the host) for every allreduce_sum issued since
+                    the previous wait_all.
+     allgather      dst[r*count .. (r+1)*count) <- rank r's src[0..count); ordered on `stream`: work enqueued on `stream`
+                    afterwards sees dst.
+   Each returns 0 or a non-zero error code (the step then fails with -30).  exact != 0: batch-norm statistics are combined over
+   all ranks in rank order (SyncBN, bitwise the 1-GPU statistics for power-of-two shards) and the MinibatchLayer sees the whole
+   global minibatch (layers.py:506-524) -- the N-GPU step is then the same function of the global minibatch as the reference's
+   step; exact == 0: local statistics (faster, NOT the reference's arithmetic).  Call BEFORE ian_trainer_finalize. */
+typedef struct ian_comm_ops {
+  int32_t world, rank;
+  void* ctx;
+  int (*allreduce_sum)(void* ctx, float* buf, int64_t count, void* stream);
+  int (*wait_all)(void* ctx, void* stream);
+  int (*allgather)(void* ctx, const float* src, float* dst, int64_t count, void* stream);
+} ian_comm_ops;
+int ian_trainer_set_comm(ian_trainer* t, const ian_comm_ops* ops, int32_t exact);
 /* GANcheckpoints.py:33-57: one call per npz entry, Theano parameter names (trainable parameters, "<bn>.mean|inv_std",
    "l_IAF_{mu,ls}_{input,output_W,output_D}.{W,b}"); host pointer. */
 int ian_trainer_load_param(ian_trainer* t, const char* name, const float* data, int64_t numel);
@@ -204,12 +231,44 @@ int ian_trainer_finalize(ian_trainer* t);
    them synchronises `stream`).  0 / negative, text via ian_trainer_last_error. */
 int ian_train_step(ian_trainer* t, int32_t which, const float* x, const float* zrand, const float* eps, int32_t n, float* metrics,
                    void* stream);
+/* The same step in pieces, for tests and diagnostics (ian_train_step == forward, [metrics], backward, finish_allreduce,
+   regularizers, apply_adam on one stream).  xhat_override / xgen_override (device, (n,3,64,64), or NULL): images fed to the
+   encoder passes on X_hat / X_gen instead of the decoder outputs (the decoders still run) -- the discriminator's |a_b - a_b'|
+   kernels and the leaky-ReLU kinks make the gradients discontinuous in the activations, so a parity test feeds both
+   implementations the SAME images. */
+int ian_trainer_forward(ian_trainer* t, const float* x, const float* zrand, const float* eps, int32_t n, const float* xhat_override,
+                        const float* xgen_override, void* stream);
+int ian_trainer_metrics(ian_trainer* t, float* metrics);
+int ian_trainer_backward(ian_trainer* t, int32_t which);
+int ian_trainer_finish_allreduce(ian_trainer* t, int32_t which);
+int ian_trainer_regularizers(ian_trainer* t, int32_t which);
+int ian_trainer_apply_adam(ian_trainer* t, int32_t which);
+/* one encoder backward sweep: pass 0 = encoder(X), 1 = encoder(X_hat), 2 = encoder(X_gen); cross-entropy seeds
+   dlogits = w0 (p - onehot(t0)) + w1 (p - onehot(t1)) (t < 0: none); reset != 0 starts a fresh gradient sweep first */
+int ian_trainer_enc_backward(ian_trainer* t, int32_t pass, int32_t t0, float w0, int32_t t1, float w1, int32_t feature_seeded,
+                             int32_t want_w, int32_t want_dx, int32_t reset);
+/* device address of an internal buffer: "<pass>.<name>", pass in EX EH EG ZS DZ DG (csrc/ian_trainer.cpp *_alloc),
+   "<pass>.<bn>.<mean|inv_std|scale|shift>" (float32 [C]) or ".<sums|bsums>" (float64 [2][C]), "scalars", "ws_loss" */
+int ian_trainer_buffer(ian_trainer* t, const char* name, void** ptr, int64_t* numel);
+/* flat device buffers of group 0 encoder_params, 1 Z_params, 2 decoder_params (p, gradient, Adam m, v) or 3 = batch-norm
+   running averages (p only); reference layouts, offsets via ian_trainer_param_info */
+int ian_trainer_group(ian_trainer* t, int32_t group, float** p, float** g, float** m, float** v, int64_t* numel);
+int ian_trainer_param_info(ian_trainer* t, const char* name, int32_t* group, int64_t* offset, int64_t* numel);
+/* parameters of `group` were written behind the trainer's back: repack before the next forward */
+int ian_trainer_mark_dirty(ian_trainer* t, int32_t group);
+/* "exposed_ms_gen|discrim" (mean stall of the compute stream on the gradient all-reduce, option measure_exposed),
+   "plan_buckets_gen|discrim", "overlap_log", "world", "rank", "exact", "global_batch" */
+int ian_trainer_stat(ian_trainer* t, const char* key, double* out);
+/* rec[6] = which, group, first element, bytes, gradient write after which the bucket was handed over, writes of that sweep */
+int ian_trainer_overlap_log(ian_trainer* t, int32_t index, int64_t* rec);
 /* per-layer (tile shape x split-K x K-loop schedule) choice for this batch on this GPU, as ian_layer_autotune */
 int ian_trainer_autotune(ian_trainer* t, void* stream);
 /* copy a parameter / running average (grad = 0) or its gradient of the last step (grad = 1) to the host (checkpoints:
    train_IAN.py:563-569; tests) */
 int ian_trainer_read_param(ian_trainer* t, const char* name, int32_t grad, float* out, int64_t numel);
-/* "learning_rate" (schedule, train_IAN.py:523-527), "head6", "update_running"; "overlap_wgrad" (default 1): weight-gradient
+/* "overlap" (default 1: gradient buckets are handed to allreduce_sum while backward still runs), "bucket_bytes" (16 MB),
+   "measure_exposed";
+   "learning_rate" (schedule, train_IAN.py:523-527), "head6", "update_running"; "overlap_wgrad" (default 1): weight-gradient
    GEMMs go to a second HIP stream owned by the trainer and are joined before the regularizers and Adam -- same launches, same
    numbers, bitwise (tests/test_gpu_ctrainer.py); 0 keeps everything on the caller's stream */
 int ian_trainer_set_option(ian_trainer* t, const char* key, double value);

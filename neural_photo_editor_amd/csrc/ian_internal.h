@@ -325,20 +325,20 @@ struct ColStatsArgs {
   const float* y;  // raw (pre-batch-norm) value, mode 1
   const float* mean;
   const float* inv_std;
-  float* partial;  // [nchunks][2][C]
+  double* partial; // [nchunks][2][C] float64 partial sums (kernels_train.hip: NUMERICS)
   long long rows;
   int C, stride, mode, act;
 };
-hipError_t launch_colstats(const ColStatsArgs& a, int nchunks, float* sums, hipStream_t s);
+hipError_t launch_colstats(const ColStatsArgs& a, int nchunks, double* sums, hipStream_t s);
 // single-process batch-norm statistics, second stage fused (kernels_train.hip: bn_finish_kernel / bn_bwd_finish_kernel)
-hipError_t launch_bn_stats_affine(const ColStatsArgs& a, int nchunks, float* sums, float count, float eps, const float* gamma,
+hipError_t launch_bn_stats_affine(const ColStatsArgs& a, int nchunks, double* sums, float count, float eps, const float* gamma,
                                   const float* beta, float* mean, float* inv_std, float* scale, float* shift, float* run_mean,
                                   float* run_inv_std, float keep, float alpha, hipStream_t s);
-hipError_t launch_bn_bwd_stats(const ColStatsArgs& a, int nchunks, float* sums, float* gbeta, int acc_beta, float* ggamma,
+hipError_t launch_bn_bwd_stats(const ColStatsArgs& a, int nchunks, double* sums, float* gbeta, int acc_beta, float* ggamma,
                                int acc_gamma, hipStream_t s);
 // out[i] = pairwise tree over k < count of partial[k*width + i] (fixed order: see kernels_train.hip)
-hipError_t launch_tree_sum(const float* partial, int count, int width, float* out, hipStream_t s);
-hipError_t launch_bn_make_affine(const float* sums, float count, float eps, const float* gamma, const float* beta,
+hipError_t launch_tree_sum(const double* partial, int count, int width, double* out, hipStream_t s);
+hipError_t launch_bn_make_affine(const double* sums, float count, float eps, const float* gamma, const float* beta,
                                  int C, float* mean, float* inv_std, float* scale, float* shift, hipStream_t s);
 struct BnBwdArgs {
   const float* dA;
@@ -347,7 +347,7 @@ struct BnBwdArgs {
   const float* mean;
   const float* inv_std;
   const float* scale;
-  const float* sums;  // [2][C] (sum g, sum g*xhat) or nullptr: activation backward only
+  const double* sums; // [2][C] float64 (sum g, sum g*xhat) or nullptr: activation backward only
   float* dy;
   long long rows;
   int C, stride, act;
@@ -355,6 +355,7 @@ struct BnBwdArgs {
 };
 hipError_t launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s);
 hipError_t launch_axpy(float alpha, const float* x, float* y, long long n, int accumulate, hipStream_t s);
+hipError_t launch_axpy_f64(double alpha, const double* x, float* y, long long n, int accumulate, hipStream_t s);
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int n, int hw, int c, int stride, hipStream_t s);
 hipError_t launch_globalpool(const float* x, float* y, int n, int hw, int C, int xs, int ys, hipStream_t s);
 hipError_t launch_globalpool_bwd(const float* dy, float* dx, int n, int hw, int C, int xs, int ys, int accumulate,

@@ -29,7 +29,7 @@ extern "C" {
 const char* ian_k_last_error(void) { return g_err.c_str(); }
 
 int ian_k_colstats(int32_t mode, const float* x, const float* a, const float* y, const float* mean, const float* inv_std,
-                   int64_t rows, int32_t C, int32_t stride, int32_t act, float* workspace, int32_t nchunks, float* sums,
+                   int64_t rows, int32_t C, int32_t stride, int32_t act, double* workspace, int32_t nchunks, double* sums,
                    void* stream) {
   if (!x || !workspace || !sums || rows <= 0 || C <= 0 || (C & 3) || nchunks <= 0 || mode < 0 || mode > 2) return bad("ian_k_colstats");
   if (mode >= 1 && act != IAN_ACT_NONE && !a) return bad("ian_k_colstats (activation output missing)");
@@ -41,18 +41,18 @@ int ian_k_colstats(int32_t mode, const float* x, const float* a, const float* y,
   return chk(launch_colstats(s, nchunks, sums, ST), "ian_k_colstats");
 }
 
-int ian_k_tree_sum(const float* partial, int32_t count, int32_t width, float* out, void* stream) {
+int ian_k_tree_sum(const double* partial, int32_t count, int32_t width, double* out, void* stream) {
   if (!partial || !out || count <= 0 || width <= 0 || count >= 65536) return bad("ian_k_tree_sum");
   return chk(launch_tree_sum(partial, count, width, out, ST), "ian_k_tree_sum");
 }
 
-int ian_k_bn_make_affine(const float* sums, float count, float eps, const float* gamma, const float* beta, int32_t C,
+int ian_k_bn_make_affine(const double* sums, float count, float eps, const float* gamma, const float* beta, int32_t C,
                          float* mean, float* inv_std, float* scale, float* shift, void* stream) {
   if (!sums || !gamma || !beta || !mean || !inv_std || !scale || !shift || C <= 0 || count <= 0) return bad("ian_k_bn_make_affine");
   return chk(launch_bn_make_affine(sums, count, eps, gamma, beta, C, mean, inv_std, scale, shift, ST), "ian_k_bn_make_affine");
 }
 
-int ian_k_bn_stats_affine(const float* y, int64_t rows, int32_t C, int32_t stride, float* workspace, int32_t nchunks, float* sums,
+int ian_k_bn_stats_affine(const float* y, int64_t rows, int32_t C, int32_t stride, double* workspace, int32_t nchunks, double* sums,
                           float count, float eps, const float* gamma, const float* beta, float* mean, float* inv_std, float* scale,
                           float* shift, float* run_mean, float* run_inv_std, float keep, float alpha, void* stream) {
   if (!y || !workspace || !sums || !gamma || !beta || !mean || !inv_std || !scale || !shift || rows <= 0 || C <= 0 || (C & 3) ||
@@ -68,7 +68,7 @@ int ian_k_bn_stats_affine(const float* y, int64_t rows, int32_t C, int32_t strid
 }
 
 int ian_k_bn_bwd_stats(const float* dA, const float* a, const float* y, const float* mean, const float* inv_std, int64_t rows, int32_t C,
-                       int32_t stride, int32_t act, float* workspace, int32_t nchunks, float* sums, float* gbeta, int32_t acc_beta,
+                       int32_t stride, int32_t act, double* workspace, int32_t nchunks, double* sums, float* gbeta, int32_t acc_beta,
                        float* ggamma, int32_t acc_gamma, void* stream) {
   if (!dA || !y || !mean || !inv_std || !workspace || !sums || rows <= 0 || C <= 0 || (C & 3) || nchunks <= 0 || (!gbeta) != (!ggamma))
     return bad("ian_k_bn_bwd_stats");
@@ -87,7 +87,7 @@ int ian_k_affine(const float* x, float* y, const float* scale, const float* shif
 }
 
 int ian_k_bn_bwd(const float* dA, const float* a, const float* y, const float* mean, const float* inv_std,
-                 const float* scale, const float* sums, float count, float* dy, int64_t rows, int32_t C, int32_t stride,
+                 const float* scale, const double* sums, float count, float* dy, int64_t rows, int32_t C, int32_t stride,
                  int32_t act, void* stream) {
   if (!dA || !dy || rows <= 0 || C <= 0 || (C & 3)) return bad("ian_k_bn_bwd");
   if (act != IAN_ACT_NONE && !a) return bad("ian_k_bn_bwd (activation output missing)");
@@ -101,6 +101,11 @@ int ian_k_bn_bwd(const float* dA, const float* a, const float* y, const float* m
 int ian_k_axpy(float alpha, const float* x, float* y, int64_t n, int32_t accumulate, void* stream) {
   if (!x || !y || n <= 0) return bad("ian_k_axpy");
   return chk(launch_axpy(alpha, x, y, n, accumulate, ST), "ian_k_axpy");
+}
+
+int ian_k_axpy_f64(double alpha, const double* x, float* y, int64_t n, int32_t accumulate, void* stream) {
+  if (!x || !y || n <= 0) return bad("ian_k_axpy_f64");
+  return chk(launch_axpy_f64(alpha, x, y, n, accumulate, ST), "ian_k_axpy_f64");
 }
 
 int ian_k_gather(const float* src, const int32_t* map, float* dst, int64_t count, void* stream) {

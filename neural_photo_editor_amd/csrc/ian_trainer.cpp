@@ -3,11 +3,22 @@
 // device buffers for the minibatch; the three Adam groups, every activation, the batch-norm running averages and the frozen
 // MADE parameters live inside the object.
 //
-// The wiring is the one neural_photo_editor_amd/trainer.py sequences from Python (and that tests/test_gpu_train*.py hold
-// against the float64 twin and the reference-executed fixtures): same ian_layer_* / ian_k_* launches in the same order, so
-// a step here is bitwise the step there (tests/test_gpu_ctrainer.py).  This file uses only the public C ABI of
-// include/ian_train.h plus hipMalloc / hipMemcpy.  Single process: the data-parallel step (gradient buckets overlapped
-// with backward, SyncBN, MinibatchLayer all-gather over RCCL) stays in trainer.py, where torch.distributed provides RCCL.
+// This is the ONE sequencer of the training step (round 4: neural_photo_editor_amd/trainer.py is a thin ctypes caller of it,
+// no second wiring exists).  It uses only the public C ABI of include/ian_train.h plus hipMalloc / hipMemcpy / streams / events.
+//
+// Data parallel (train_IAN.py has none): one process per GPU, the minibatch is sharded, losses are means over the
+// GLOBAL batch.  The collectives arrive through a small callback table (ian_comm_ops: allreduce_sum / wait_all / allgather on
+// device buffers and HIP streams) that the host fills -- from torch.distributed (backend "nccl" = RCCL over xGMI; gloo in the
+// tests) in neural_photo_editor_amd/trainer.py -- so the same entry, ian_train_step, runs at world size 1 and N:
+//   * gradient all-reduce OVERLAPPED with backward: a group's flat gradient buffer is cut into buckets (16 MB); the first
+//     sweep of each update kind records the order of gradient writes; from then on a bucket is handed to allreduce_sum on a
+//     side stream the moment its LAST writer kernel has been issued (events on the compute stream and on the weight-gradient
+//     stream), while the compute stream goes on; the compute stream waits (wait_all) only before the regularisers and Adam;
+//   * exact = 1 (SyncBN + MinibatchLayer all-gather): the float64 batch-statistics sums of every normalisation are
+//     all-gathered and combined in RANK ORDER by the same pairwise tree the per-rank reduction uses (bitwise the
+//     single-process statistics for power-of-two shards), the MinibatchLayer activations and their gradients are
+//     all-gathered (layers.py:506-524 couples the whole minibatch), which makes the N-GPU step the same function of the
+//     global minibatch as the reference's 1-GPU step;  exact = 0: local statistics, NOT the reference's arithmetic.
 //
 // Graph (train_IAN.py:116-149): encoder(X) -> z ~ N(mu, e^ls) -> IAF -> decoder -> X_hat; encoder(X_hat);
 // decoder(IAF(Z)) -> X_gen; encoder(X_gen); every pass in batch-statistics batch-norm mode.
@@ -19,6 +30,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <deque>
 #include <map>
 #include <set>
 #include <string>
@@ -71,7 +83,8 @@ struct Group {  // one Adam instance: flat device buffers in the reference (Thea
 
 struct BN {  // Lasagne batch_norm in training mode: state of one normalisation in one pass
   int C = 0;
-  float *sums = nullptr, *bsums = nullptr, *mean = nullptr, *inv_std = nullptr, *scale = nullptr, *shift = nullptr;
+  double *sums = nullptr, *bsums = nullptr;   // float64 column sums (kernels_train.hip NUMERICS)
+  float *mean = nullptr, *inv_std = nullptr, *scale = nullptr, *shift = nullptr;
   float count = 1.f;
 };
 
@@ -81,6 +94,15 @@ struct LayerRef {
 };
 
 typedef std::map<std::string, float*> Bufs;
+
+struct Bucket {  // a slice of one group's flat gradient buffer = one all-reduce message
+  int group;     // 0 encoder_params, 1 Z_params, 2 decoder_params
+  int64_t lo, hi;
+  std::set<std::string> names;
+  int ready;     // index (1-based) of the last gradient write that lands in [lo, hi); 0: nothing writes it
+  bool fired;
+};
+struct OverlapRec { int which, group; int64_t lo, bytes; int issued_at_write, writes_in_backward; };
 
 }  // namespace
 
@@ -96,14 +118,16 @@ struct ian_trainer {
   std::map<std::string, LayerRef> layers;
   std::vector<std::string> layer_order;
   std::vector<float*> allocs;
+  std::map<const void*, size_t> alloc_floats;      // size of every allocation (ian_trainer_buffer)
   std::vector<float> masks[3];
   int made_n = 0;
   float *made_w = nullptr, *made_b = nullptr;
   int32_t *fc2_perm = nullptr, *fc2_inv = nullptr;
-  float *fc2_bias = nullptr, *fc2_db = nullptr, *tmp_big = nullptr;
-  float *ws_stats = nullptr, *ws_loss = nullptr, *scalars = nullptr, *mb_W = nullptr, *mb_dW = nullptr, *mb_colscale = nullptr,
-        *tmp_vals = nullptr;
-  size_t ws_stats_cap = 0;
+  float *fc2_bias = nullptr, *fc2_db = nullptr, *fc2_tmp = nullptr;
+  double *ws_stats = nullptr, *tmp_vals = nullptr, *tmp_big = nullptr, *gbuf = nullptr;   // float64 statistics workspaces
+  float *ws_loss = nullptr, *scalars = nullptr, *mb_W = nullptr, *mb_dW = nullptr, *mb_colscale = nullptr, *ortho_vals = nullptr;
+  size_t ws_stats_cap = 0, gbuf_cap = 0;
+  bool oom = false;                                 // a device allocation failed (checked at the end of finalize)
   std::set<std::string> dirty, touched;
   Bufs EX, EH, EG, ZS, DZ, DG;
   std::map<std::string, BN> bnEX, bnEH, bnEG, bnZ, bnDZ, bnDG;
@@ -120,6 +144,27 @@ struct ian_trainer {
   hipStream_t st2 = nullptr;
   std::vector<hipEvent_t> events;
   size_t ev_used = 0;
+  hipStream_t last_stream = nullptr;               // stream of the previous entry: a different one is synchronised first
+  bool have_last_stream = false;
+  // ---- data parallel ------------------------------------------------------------------------------------------------
+  ian_comm_ops comm;
+  int world = 1, rank = 0, exact = 0, N = 0;        // N = global batch (losses are means over it)
+  int overlap = 1;                                  // hand gradient buckets to the all-reduce while backward still runs
+  int64_t bucket_bytes = 16 << 20;                  // xGMI is point-to-point: a few large messages
+  hipStream_t st_comm = nullptr;                    // side stream the buckets are handed over on
+  std::map<int, std::vector<Bucket>> plans;         // per update kind (0 gen, 1 discrim)
+  std::map<int, int> plan_key;
+  std::vector<Bucket>* buckets = nullptr;           // the plan this sweep follows (nullptr: record, reduce at the end)
+  std::vector<std::vector<std::string>> evlog;      // gradient writes of this sweep, in issue order
+  int which_now = 0, nfired = 0;
+  std::deque<OverlapRec> overlap_log;               // last few sweeps (tests/test_gpu_dp.py, bench.py)
+  int measure_exposed = 0;
+  hipEvent_t ex0 = nullptr, ex1 = nullptr;
+  bool ex_pending = false;
+  int ex_which = 0;
+  double exposed_ms[2] = {0, 0};
+  int exposed_n[2] = {0, 0};
+  const float *xhat_override = nullptr, *xgen_override = nullptr;   // test hook of ian_trainer_forward
 };
 
 namespace {
@@ -149,13 +194,23 @@ int tfail(ian_trainer* t, int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return tfail(t, -20, "%s: %s", #expr, hipGetErrorString(e_));              \
   } while (0)
 
-float* dalloc(ian_trainer* t, size_t floats) {
+float* dalloc(ian_trainer* t, size_t floats) {   // zero-filled device floats; a failure sets t->oom (finalize reports it)
   float* p = nullptr;
-  if (hipMalloc((void**)&p, (floats ? floats : 1) * sizeof(float)) != hipSuccess) return nullptr;
-  (void)hipMemset(p, 0, (floats ? floats : 1) * sizeof(float));
+  const size_t bytes = (floats ? floats : 1) * sizeof(float);
+  if (hipMalloc((void**)&p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    t->oom = true;
+    return nullptr;
+  }
+  if (hipMemset(p, 0, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    t->oom = true;
+  }
   t->allocs.push_back(p);
+  t->alloc_floats[p] = floats;
   return p;
 }
+double* dalloc64(ian_trainer* t, size_t doubles) { return reinterpret_cast<double*>(dalloc(t, 2 * doubles)); }
 
 void add_param(ian_trainer* t, Group& g, const std::string& name, std::vector<int64_t> shape) {
   Shape s{shape};
@@ -288,7 +343,7 @@ ian_layer* lay(ian_trainer* t, const std::string& n) { return t->layers.at(n).l;
 BN make_bn(ian_trainer* t, int C) {
   BN b;
   b.C = C;
-  b.sums = dalloc(t, 2 * C); b.bsums = dalloc(t, 2 * C);
+  b.sums = dalloc64(t, 2 * C); b.bsums = dalloc64(t, 2 * C);
   b.mean = dalloc(t, C); b.inv_std = dalloc(t, C); b.scale = dalloc(t, C); b.shift = dalloc(t, C);
   return b;
 }
@@ -308,6 +363,10 @@ void enc_alloc(ian_trainer* t, Bufs& E, std::map<std::string, BN>& bn) {
   E["feat"] = dalloc(t, n * 1024); E["dfeat"] = dalloc(t, n * 1024);
   E["act"] = dalloc(t, n * cs(2500)); E["dact"] = dalloc(t, n * cs(2500));
   E["mb"] = dalloc(t, n * cs(1524)); E["dmb"] = dalloc(t, n * cs(1524));
+  if (t->exact) {  // MinibatchLayer over the GLOBAL minibatch (layers.py:506-524): all ranks' activations / feature gradients
+    E["act_all"] = dalloc(t, (size_t)t->N * cs(2500));
+    E["dmb_all"] = dalloc(t, (size_t)t->N * cs(1524));
+  }
   E["p"] = dalloc(t, n * 3); E["loss"] = dalloc(t, n * 4); E["dlogits"] = dalloc(t, n * 4);
 }
 void z_alloc(ian_trainer* t) {
@@ -368,62 +427,249 @@ int chunks(const ian_trainer* t, int64_t rows) {
   if (rows == (int64_t)t->n * rpi) return (int)(t->n * (rpi / 512 > 0 ? rpi / 512 : 1));
   return (int)(rows < 256 ? rows : 256);
 }
-int ws_for(ian_trainer* t, int64_t rows, int C, float** out) {
+int ws_for(ian_trainer* t, int64_t rows, int C, double** out) {
   const size_t need = (size_t)chunks(t, rows) * 2 * C;
   if (t->ws_stats_cap < need) {
-    t->ws_stats = dalloc(t, need);
-    if (!t->ws_stats) return tfail(t, -20, "out of device memory (statistics workspace)");
+    double* p = dalloc64(t, need);
+    if (!p) return tfail(t, -20, "out of device memory (statistics workspace)");
+    t->ws_stats = p;
     t->ws_stats_cap = need;
   }
   *out = t->ws_stats;
   return 0;
 }
+Group& group_of(ian_trainer* t, int g) { return g == 0 ? t->enc : (g == 1 ? t->zp : t->dec); }
+int group_index(ian_trainer* t, const Group* g) { return g == &t->enc ? 0 : (g == &t->zp ? 1 : 2); }
+int next_event(ian_trainer* t, hipEvent_t* e) {
+  if (t->ev_used == t->events.size()) {
+    hipEvent_t ne;
+    THIP(hipEventCreateWithFlags(&ne, hipEventDisableTiming));
+    t->events.push_back(ne);
+  }
+  *e = t->events[t->ev_used++];
+  return 0;
+}
+
+// ---- gradient all-reduce overlapped with backward ----------------------------------------------------------
+// encoder_params receive contributions from three encoder passes, decoder_params from two decoder passes, so the "last" writer
+// of a bucket is a property of the whole backward sweep of an update kind: every gradient write is reported through mark();
+// the first sweep of a kind records the order, later sweeps fire a bucket right after its last write.
+int fire(ian_trainer* t, Bucket& b) {
+  Group& g = group_of(t, b.group);
+  hipEvent_t e;
+  int rc;
+  if ((rc = next_event(t, &e))) return rc;
+  THIP(hipEventRecord(e, t->st));                  // after the bucket's last writer on the compute stream ...
+  THIP(hipStreamWaitEvent(t->st_comm, e, 0));
+  if (t->overlap_wgrad && t->st2) {                // ... and on the weight-gradient stream
+    if ((rc = next_event(t, &e))) return rc;
+    THIP(hipEventRecord(e, t->st2));
+    THIP(hipStreamWaitEvent(t->st_comm, e, 0));
+  }
+  rc = t->comm.allreduce_sum(t->comm.ctx, g.g + b.lo, b.hi - b.lo, t->st_comm);
+  if (rc) return tfail(t, -30, "comm.allreduce_sum failed (%d) on a gradient bucket of group %d", rc, b.group);
+  b.fired = true;
+  ++t->nfired;
+  t->overlap_log.push_back({t->which_now, b.group, b.lo, 4 * (b.hi - b.lo), (int)t->evlog.size(), 0});
+  while (t->overlap_log.size() > 256) t->overlap_log.pop_front();
+  return 0;
+}
+int mark(ian_trainer* t, const std::vector<std::string>& names) {  // the gradients of `names` have just been written (issued)
+  for (auto& n : names) t->touched.insert(n);
+  t->evlog.push_back(names);
+  if (!t->buckets) return 0;
+  const int ev = (int)t->evlog.size();
+  for (Bucket& b : *t->buckets) {
+    if (b.fired) {
+      for (auto& n : names)
+        if (b.names.count(n)) {
+          t->plans.erase(t->which_now);            // stale plan: the next sweep of this kind re-records it
+          t->buckets = nullptr;
+          return tfail(t, -31, "gradient of %s written after its bucket was handed to the all-reduce (write order changed since the "
+                               "plan was recorded; plan dropped)", n.c_str());
+        }
+    } else if (b.ready == ev) {
+      int rc = fire(t, b);
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}
+std::vector<Bucket> make_plan(ian_trainer* t, int which) {  // buckets of the groups this update kind moves, with their last writes
+  std::map<std::string, int> last;
+  for (size_t i = 0; i < t->evlog.size(); ++i)
+    for (auto& n : t->evlog[i]) last[n] = (int)i + 1;
+  const int64_t step = t->bucket_bytes / 4 > 0 ? t->bucket_bytes / 4 : 1;
+  std::vector<Bucket> plan;
+  for (int gi : {which == 0 ? 2 : 0, 1}) {
+    Group& g = group_of(t, gi);
+    for (int64_t o = 0; o < g.numel; o += step) {
+      Bucket b;
+      b.group = gi; b.lo = o; b.hi = o + step < g.numel ? o + step : g.numel; b.ready = 0; b.fired = false;
+      for (auto& nm : g.names) {
+        const auto& of = g.off.at(nm);
+        const int64_t po = of.first, cnt = of.second.numel();
+        if (po < b.hi && po + cnt > b.lo) {
+          b.names.insert(nm);
+          auto it = last.find(nm);
+          if (it != last.end() && it->second > b.ready) b.ready = it->second;
+        }
+      }
+      plan.push_back(b);
+    }
+  }
+  return plan;
+}
+int begin_backward(ian_trainer* t, int which) {
+  t->touched.clear();
+  t->evlog.clear();
+  t->which_now = which;
+  t->nfired = 0;
+  t->buckets = nullptr;
+  if (t->world == 1) return 0;
+  // the recorded write order depends on these switches: a plan made under other settings is discarded
+  const int key = (t->head6 ? 1 : 0) | (t->exact ? 2 : 0) | (t->update_running ? 4 : 0) | (t->overlap_wgrad ? 8 : 0);
+  if (!t->plan_key.count(which) || t->plan_key[which] != key) {
+    t->plans.erase(which);
+    t->plan_key[which] = key;
+  }
+  if (!t->overlap || !t->plans.count(which)) return 0;
+  t->buckets = &t->plans[which];
+  for (Bucket& b : *t->buckets) b.fired = false;
+  for (Bucket& b : *t->buckets)
+    if (b.ready == 0) {
+      int rc = fire(t, b);
+      if (rc) return rc;
+    }
+  return 0;
+}
+int join_side_stream(ian_trainer* t);
+int finish_allreduce(ian_trainer* t, int which) {  // after backward: reduce what has not been handed over yet, then the compute stream waits
+  int rc;
+  if ((rc = join_side_stream(t))) return rc;
+  if (t->world == 1) return 0;
+  if (!t->buckets) {                               // first sweep of this kind (or overlap off): plan, then reduce everything
+    t->plans[which] = make_plan(t, which);
+    t->buckets = &t->plans[which];
+    for (Bucket& b : *t->buckets) b.fired = false;
+  }
+  for (Bucket& b : *t->buckets)
+    if (!b.fired && (rc = fire(t, b))) return rc;
+  const int writes = (int)t->evlog.size();
+  for (size_t i = t->overlap_log.size() >= (size_t)t->nfired ? t->overlap_log.size() - t->nfired : 0; i < t->overlap_log.size(); ++i)
+    t->overlap_log[i].writes_in_backward = writes;
+  // how long the COMPUTE stream stalls on communication = the part of the all-reduce backward did not hide
+  if (t->measure_exposed && t->ex_pending) {       // fold the previous measurement in (its events have completed long ago)
+    float ms = 0.f;
+    if (hipEventSynchronize(t->ex1) == hipSuccess && hipEventElapsedTime(&ms, t->ex0, t->ex1) == hipSuccess) {
+      t->exposed_ms[t->ex_which] += ms;
+      t->exposed_n[t->ex_which] += 1;
+    }
+    (void)hipGetLastError();
+    t->ex_pending = false;
+  }
+  if (t->measure_exposed) {
+    if (!t->ex0) { THIP(hipEventCreate(&t->ex0)); THIP(hipEventCreate(&t->ex1)); }
+    THIP(hipEventRecord(t->ex0, t->st));
+  }
+  rc = t->comm.wait_all(t->comm.ctx, t->st);
+  if (rc) return tfail(t, -30, "comm.wait_all failed (%d)", rc);
+  if (t->measure_exposed) {
+    THIP(hipEventRecord(t->ex1, t->st));
+    t->ex_pending = true;
+    t->ex_which = which;
+  }
+  t->buckets = nullptr;
+  return 0;
+}
+// sums (float64 [width]) <- sum over ranks, combined in RANK ORDER by the pairwise tree of ian_k_tree_sum: the result does not depend
+// on the collective's internal algorithm and, for power-of-two shards, equals the single-process reduction bit for bit (SyncBN)
+int allreduce_ordered(ian_trainer* t, double* sums, int width) {
+  if (t->world == 1) return 0;
+  const size_t need = (size_t)width * t->world;
+  if (t->gbuf_cap < need) {
+    double* p = dalloc64(t, need);
+    if (!p) return tfail(t, -20, "out of device memory (statistics gather buffer)");
+    t->gbuf = p;
+    t->gbuf_cap = need;
+  }
+  const int rc = t->comm.allgather(t->comm.ctx, reinterpret_cast<const float*>(sums), reinterpret_cast<float*>(t->gbuf), 2 * (int64_t)width, t->st);
+  if (rc) return tfail(t, -30, "comm.allgather failed (%d) on batch statistics", rc);
+  TK(ian_k_tree_sum(t->gbuf, t->world, width, sums, t->st));
+  return 0;
+}
+
 int acc(ian_trainer* t, const std::string& pname, const float* src, int64_t count, float alpha = 1.f) {  // grad[pname] (+)= alpha * src
   TK(ian_k_axpy(alpha, src, G(t, pname), count, t->touched.count(pname) ? 1 : 0, t->st));
-  t->touched.insert(pname);
-  return 0;
+  return mark(t, {pname});
+}
+int acc64(ian_trainer* t, const std::string& pname, const double* src, int64_t count, double alpha = 1.0) {  // from float64 column sums
+  TK(ian_k_axpy_f64(alpha, src, G(t, pname), count, t->touched.count(pname) ? 1 : 0, t->st));
+  return mark(t, {pname});
 }
 int bn_forward(ian_trainer* t, BN& bn, const float* y, float* a, int64_t rows, int C, int stride, const float* gamma, const float* beta, int act,
                int64_t count_rows, const char* running) {
-  float* ws;
+  double* ws;
   int rc;
   if ((rc = ws_for(t, rows, C, &ws))) return rc;
-  bn.count = (float)count_rows;
   float *rm = nullptr, *ri = nullptr;
   if (running && t->update_running) {  // r = (1 - alpha) r + alpha * batch   (Lasagne BatchNormLayer alpha = 0.1)
     rm = P(t, std::string(running) + ".mean");
     ri = P(t, std::string(running) + ".inv_std");
   }
-  TK(ian_k_bn_stats_affine(y, rows, C, stride, ws, chunks(t, rows), bn.sums, bn.count, BN_EPS, gamma, beta, bn.mean, bn.inv_std, bn.scale,
-                           bn.shift, rm, ri, 0.9f, 0.1f, t->st));
+  if (!t->exact) {  // no collective between the two stages: one fused second stage
+    bn.count = (float)count_rows;
+    TK(ian_k_bn_stats_affine(y, rows, C, stride, ws, chunks(t, rows), bn.sums, bn.count, BN_EPS, gamma, beta, bn.mean, bn.inv_std, bn.scale,
+                             bn.shift, rm, ri, 0.9f, 0.1f, t->st));
+    TK(ian_k_affine(y, a, bn.scale, bn.shift, rows, C, stride, act, t->st));
+    return 0;
+  }
+  TK(ian_k_colstats(0, y, nullptr, nullptr, nullptr, nullptr, rows, C, stride, 0, ws, chunks(t, rows), bn.sums, t->st));
+  if ((rc = allreduce_ordered(t, bn.sums, 2 * C))) return rc;
+  bn.count = (float)(count_rows * t->world);
+  TK(ian_k_bn_make_affine(bn.sums, bn.count, BN_EPS, gamma, beta, C, bn.mean, bn.inv_std, bn.scale, bn.shift, t->st));
   TK(ian_k_affine(y, a, bn.scale, bn.shift, rows, C, stride, act, t->st));
+  if (rm) {
+    TK(ian_k_axpy(0.9f, rm, rm, C, 0, t->st)); TK(ian_k_axpy(0.1f, bn.mean, rm, C, 1, t->st));
+    TK(ian_k_axpy(0.9f, ri, ri, C, 0, t->st)); TK(ian_k_axpy(0.1f, bn.inv_std, ri, C, 1, t->st));
+  }
   return 0;
 }
 int bn_backward(ian_trainer* t, BN& bn, const float* dA, const float* a, const float* y, float* dy, int64_t rows, int C, int stride, int act,
                 const std::string& gname, const std::string& bname, bool want_w) {
-  float* ws;
+  double* ws;
   int rc;
   if ((rc = ws_for(t, rows, C, &ws))) return rc;
-  float *gb = nullptr, *gg = nullptr;
-  int ab = 0, ag = 0;
-  if (want_w) {
-    gb = G(t, bname); gg = G(t, gname);
-    ab = t->touched.count(bname) ? 1 : 0; ag = t->touched.count(gname) ? 1 : 0;
-    t->touched.insert(bname); t->touched.insert(gname);
+  if (!t->exact) {
+    float *gb = nullptr, *gg = nullptr;
+    int ab = 0, ag = 0;
+    if (want_w) {
+      gb = G(t, bname); gg = G(t, gname);
+      ab = t->touched.count(bname) ? 1 : 0; ag = t->touched.count(gname) ? 1 : 0;
+    }
+    TK(ian_k_bn_bwd_stats(dA, a, y, bn.mean, bn.inv_std, rows, C, stride, act, ws, chunks(t, rows), bn.bsums, gb, ab, gg, ag, t->st));
+    if (want_w && (rc = mark(t, {bname, gname}))) return rc;
+    TK(ian_k_bn_bwd(dA, a, y, bn.mean, bn.inv_std, bn.scale, bn.bsums, bn.count, dy, rows, C, stride, act, t->st));
+    return 0;
   }
-  TK(ian_k_bn_bwd_stats(dA, a, y, bn.mean, bn.inv_std, rows, C, stride, act, ws, chunks(t, rows), bn.bsums, gb, ab, gg, ag, t->st));
+  TK(ian_k_colstats(1, dA, a, y, bn.mean, bn.inv_std, rows, C, stride, act, ws, chunks(t, rows), bn.bsums, t->st));
+  if ((rc = allreduce_ordered(t, bn.bsums, 2 * C))) return rc;
+  if (want_w) {
+    // with exact statistics every rank already holds the GLOBAL dbeta / dgamma: pre-divide so that the gradient all-reduce
+    // (a sum over ranks) restores them
+    const double sc = 1.0 / t->world;
+    if ((rc = acc64(t, bname, bn.bsums, C, sc))) return rc;
+    if ((rc = acc64(t, gname, bn.bsums + C, C, sc))) return rc;
+  }
   TK(ian_k_bn_bwd(dA, a, y, bn.mean, bn.inv_std, bn.scale, bn.bsums, bn.count, dy, rows, C, stride, act, t->st));
   return 0;
 }
 int side_stream(ian_trainer* t, hipStream_t* out) {  // the stream a weight-gradient launch goes to, ordered behind what is on t->st now
   *out = t->st;
   if (!t->overlap_wgrad || !t->st2) return 0;
-  if (t->ev_used == t->events.size()) {
-    hipEvent_t e;
-    THIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    t->events.push_back(e);
-  }
-  hipEvent_t e = t->events[t->ev_used++];
+  hipEvent_t e;
+  int rc;
+  if ((rc = next_event(t, &e))) return rc;
   THIP(hipEventRecord(e, t->st));
   THIP(hipStreamWaitEvent(t->st2, e, 0));
   *out = t->st2;
@@ -431,12 +677,9 @@ int side_stream(ian_trainer* t, hipStream_t* out) {  // the stream a weight-grad
 }
 int join_side_stream(ian_trainer* t) {  // the compute stream waits for every weight gradient issued so far
   if (!t->overlap_wgrad || !t->st2 || !t->ev_used) return 0;
-  if (t->ev_used == t->events.size()) {
-    hipEvent_t e;
-    THIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    t->events.push_back(e);
-  }
-  hipEvent_t e = t->events[t->ev_used++];
+  hipEvent_t e;
+  int rc;
+  if ((rc = next_event(t, &e))) return rc;
   THIP(hipEventRecord(e, t->st2));
   THIP(hipStreamWaitEvent(t->st, e, 0));
   t->ev_used = 0;
@@ -450,8 +693,7 @@ int wgrad(ian_trainer* t, const std::string& lname, const float* x, const float*
   int rc_ = side_stream(t, &ws);
   if (rc_) return rc_;
   TL(r.l, ian_layer_backward_weight(r.l, x, dy, t->n, g.data(), (int)g.size(), t->touched.count(r.pnames[0]) ? 1 : 0, ws));
-  for (auto& p : r.pnames) t->touched.insert(p);
-  return 0;
+  return mark(t, r.pnames);
 }
 int head_backward(ian_trainer* t, const float* x, const float* dR, const float* dG, const float* dB, float* dx, bool want_w) {
   const char* names[3] = {"R", "G_a", "B_a"};
@@ -467,8 +709,10 @@ int head_backward(ian_trainer* t, const float* x, const float* dR, const float* 
                                             want_w ? (int)g[0].size() : 0, accs[0] ? 1 : 0, t->st);
     if (rc == 0) {
       if (want_w)
-        for (int i = 0; i < 3; ++i)
-          for (auto& p : t->layers.at(names[i]).pnames) t->touched.insert(p);
+        for (int i = 0; i < 3; ++i) {
+          const int mrc = mark(t, t->layers.at(names[i]).pnames);
+          if (mrc) return mrc;
+        }
       return 0;
     }
     if (rc != -4) return tfail(t, rc, "ian_layer_head6_backward failed (%d): %s", rc, ian_layer_last_error(lay(t, "R")));
@@ -497,7 +741,14 @@ int enc_forward(ian_trainer* t, Bufs& E, std::map<std::string, BN>& bn, const fl
   }
   TK(ian_k_globalpool(E["a4"], E["feat"], n, 16, 1024, 1024, 1024, t->st));
   TL(lay(t, "mb"), ian_layer_forward(lay(t, "mb"), E["feat"], n, E["act"], cs(2500), nullptr, nullptr, 0, t->st));
-  TK(ian_k_mb_forward(E["act"], n, cs(2500), 0, n, 500, 5, P(t, "minibatch_discrim.b"), E["feat"], 1024, 1024, E["mb"], cs(1524), t->st));
+  const float* act_all = E["act"];
+  int nall = n, row0 = 0;
+  if (t->exact) {  // the kernel features couple every sample with every other one of the GLOBAL minibatch (layers.py:506-520)
+    rc = t->comm.allgather(t->comm.ctx, E["act"], E["act_all"], (int64_t)n * cs(2500), t->st);
+    if (rc) return tfail(t, -30, "comm.allgather failed (%d) on the MinibatchLayer activations", rc);
+    act_all = E["act_all"]; nall = t->N; row0 = t->rank * n;
+  }
+  TK(ian_k_mb_forward(act_all, nall, cs(2500), row0, n, 500, 5, P(t, "minibatch_discrim.b"), E["feat"], 1024, 1024, E["mb"], cs(1524), t->st));
   TK(ian_k_disc_head(E["mb"], cs(1524), 1524, P(t, "discrimi.W"), n, t0, t1, acc_target, E["p"], E["loss"], t->st));
   return 0;
 }
@@ -510,12 +761,21 @@ int enc_backward(ian_trainer* t, Bufs& E, std::map<std::string, BN>& bn, int t0,
   TK(ian_k_disc_head_bwd(E["p"], P(t, "discrimi.W"), 1524, n, t0, w0, t1, w1, E["dlogits"], E["dmb"], cs(1524), t->st));
   if (want_w) {
     TK(ian_k_disc_head_wgrad(E["mb"], cs(1524), 1524, n, E["dlogits"], G(t, "discrimi.W"), t->touched.count("discrimi.W") ? 1 : 0, t->st));
-    t->touched.insert("discrimi.W");
+    if ((rc = mark(t, {"discrimi.W"}))) return rc;
     // db[k] = sum_b df[b,k] : column sums of dmb[:, 1024:1524]
     TK(ian_k_colstats(2, E["dmb"] + 1024, nullptr, nullptr, nullptr, nullptr, n, 500, cs(1524), 0, t->ws_stats, n < 256 ? n : 256, t->tmp_vals, t->st));
-    if ((rc = acc(t, "minibatch_discrim.b", t->tmp_vals, 500))) return rc;
+    if ((rc = acc64(t, "minibatch_discrim.b", t->tmp_vals, 500))) return rc;
   }
-  TK(ian_k_mb_backward(E["act"], n, cs(2500), 0, n, 500, 5, E["dmb"] + 1024, cs(1524), E["dact"], cs(2500), t->st));
+  {
+    const float *act_all = E["act"], *dmb_all = E["dmb"];
+    int nall = n, row0 = 0;
+    if (t->exact) {  // a sample's activations feed every other sample's kernel features: their gradients come from all ranks
+      rc = t->comm.allgather(t->comm.ctx, E["dmb"], E["dmb_all"], (int64_t)n * cs(1524), t->st);
+      if (rc) return tfail(t, -30, "comm.allgather failed (%d) on the MinibatchLayer gradients", rc);
+      act_all = E["act_all"]; dmb_all = E["dmb_all"]; nall = t->N; row0 = t->rank * n;
+    }
+    TK(ian_k_mb_backward(act_all, nall, cs(2500), row0, n, 500, 5, dmb_all + 1024, cs(1524), E["dact"], cs(2500), t->st));
+  }
   TK(ian_k_grad_pass(E["dmb"], cs(1524), 0, E["dfeat"], nullptr, 1024, n, 1024, 0, 0, t->st));  // direct path of the concat (layers.py:524)
   TL(lay(t, "mb"), ian_layer_backward_data(lay(t, "mb"), E["dact"], n, E["dfeat"], 1024, 1, t->st));
   if (want_w) {
@@ -523,8 +783,7 @@ int enc_backward(ian_trainer* t, Bufs& E, std::map<std::string, BN>& bn, int t0,
     TL(lay(t, "mb"), ian_layer_backward_weight(lay(t, "mb"), E["feat"], E["dact"], n, &dW, 1, 0, t->st));
     TK(ian_k_mb_weight_bwd(P(t, "minibatch_discrim.theta"), t->mb_colscale, t->mb_dW, G(t, "minibatch_discrim.theta"),
                            G(t, "minibatch_discrim.log_weight_scale"), 1024, 2500, t->touched.count("minibatch_discrim.theta") ? 1 : 0, t->st));
-    t->touched.insert("minibatch_discrim.theta");
-    t->touched.insert("minibatch_discrim.log_weight_scale");
+    if ((rc = mark(t, {"minibatch_discrim.theta", "minibatch_discrim.log_weight_scale"}))) return rc;
   }
   TK(ian_k_globalpool_bwd(E["dfeat"], E["da4"], n, 16, 1024, 1024, 1024, feature_seeded ? 1 : 0, t->st));
   for (int i = 4; i >= 2; --i) {
@@ -539,7 +798,7 @@ int enc_backward(ian_trainer* t, Bufs& E, std::map<std::string, BN>& bn, int t0,
   // enc_conv1: bias + lrelu, no batch-norm (IAN.py:71-80)
   if (want_w) {
     TK(ian_k_colstats(2, E["da1"], E["a1"], nullptr, nullptr, nullptr, (int64_t)n * 1024, 128, 128, IAN_ACT_LRELU, t->ws_stats, 256, t->tmp_vals, t->st));
-    if ((rc = acc(t, "enc_conv1.b", t->tmp_vals, 128))) return rc;
+    if ((rc = acc64(t, "enc_conv1.b", t->tmp_vals, 128))) return rc;
   }
   TK(ian_k_bn_bwd(E["da1"], E["a1"], nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, E["da1"], (int64_t)n * 1024, 128, 128, IAN_ACT_LRELU, t->st));
   if (want_w && (rc = wgrad(t, "enc_conv1", E["x"], E["da1"]))) return rc;
@@ -572,7 +831,7 @@ int z_backward(ian_trainer* t, const float* dz, const float* a4) {
   Bufs& S = t->ZS;
   int rc;
   TK(ian_k_made_iaf_bwd(S["z0"], dz, S["dz0"], t->made_w, t->made_b, n, Z, 128, t->st));
-  const float klw = 1.f / ((float)t->n * 100.f);  // d(-0.5*mean(...)): factor folded in the kernel's formula
+  const float klw = 1.f / ((float)t->N * 100.f);  // d(-0.5*mean(...)) over the GLOBAL batch: factor folded in the kernel's formula
   TK(ian_k_sample_bwd(S["mu"], S["ls"], t->eps, S["dz0"], S["dmu"], S["dls"], n, Z, 128, Z, klw, t->st));
   const char* trip[2][3] = {{"mu", "enc_mu", "mu_bnorm"}, {"ls", "enc_logsigma", "ls_bnorm"}};
   bool first = true;
@@ -689,7 +948,8 @@ int dec_backward(ian_trainer* t, Bufs& D, std::map<std::string, BN>& bn, const f
   if (want_w) {
     if ((rc = wgrad(t, "l_dec_fc2", zbuf, D["dh0"]))) return rc;
     TK(ian_k_colstats(2, D["dh0"], nullptr, nullptr, nullptr, nullptr, n, 8192, 8192, 0, t->ws_stats, n < 256 ? n : 256, t->tmp_big, t->st));
-    TK(ian_k_gather(t->tmp_big, t->fc2_inv, t->fc2_db, 8192, t->st));
+    TK(ian_k_axpy_f64(1.0, t->tmp_big, t->fc2_tmp, 8192, 0, t->st));   // float64 column sums -> float32, (H,W,C) order
+    TK(ian_k_gather(t->fc2_tmp, t->fc2_inv, t->fc2_db, 8192, t->st));
     if ((rc = acc(t, "l_dec_fc2.b", t->fc2_db, 8192))) return rc;
   }
   if (want_dz) TL(lay(t, "l_dec_fc2"), ian_layer_backward_data(lay(t, "l_dec_fc2"), D["dh0"], n, D["dz"], 128, 0, t->st));
@@ -706,16 +966,16 @@ int forward(ian_trainer* t, const float* X, const float* Zr, const float* eps) {
   if ((rc = enc_forward(t, t->EX, t->bnEX, X, 0, -1, 0, true))) return rc;  // p_X vs p1
   if ((rc = z_forward(t, t->EX["a4"], eps))) return rc;
   if ((rc = dec_forward(t, t->DZ, t->bnDZ, t->ZS["z"], true))) return rc;   // X_hat
-  if ((rc = enc_forward(t, t->EH, t->bnEH, t->DZ["xhat"], 0, 1, 1, false))) return rc;  // p_X_hat
+  if ((rc = enc_forward(t, t->EH, t->bnEH, t->xhat_override ? t->xhat_override : t->DZ["xhat"], 0, 1, 1, false))) return rc;  // p_X_hat
   TK(ian_k_grad_pass(Zr, Z, 0, t->zgen0, nullptr, 128, n, Z, 0, 0, t->st));  // (n,100) -> padded rows
   TK(ian_k_made_iaf(t->zgen0, t->zgen, t->made_w, t->made_b, n, Z, 128, t->st));  // {l_Z_IAF: Z} (train_IAN.py:149)
   if ((rc = dec_forward(t, t->DG, t->bnDG, t->zgen, false))) return rc;     // X_gen
-  return enc_forward(t, t->EG, t->bnEG, t->DG["xhat"], 0, 2, 2, false);      // p_X_gen
+  return enc_forward(t, t->EG, t->bnEG, t->xgen_override ? t->xgen_override : t->DG["xhat"], 0, 2, 2, false);  // p_X_gen
 }
 
 int metrics(ian_trainer* t, float* out9) {  // all scalar losses of train_IAN.py:169-250,279 (one device->host copy)
   const int n = t->n;
-  const float N = (float)n;
+  const float N = (float)t->N;   // means are over the GLOBAL batch
   float* s = t->scalars;
   THIP(hipMemsetAsync(s, 0, 64 * sizeof(float), t->st));
   TK(ian_k_sum_rows(t->EX["loss"], n, 4, 1.f / N, s + 0, t->st));   // [0] discrim_d_loss, [2] acc(p_X)
@@ -727,6 +987,11 @@ int metrics(ian_trainer* t, float* out9) {  // all scalar losses of train_IAN.py
     const float cnt = (float)((32 >> i) * (32 >> i) * ENC_WIDTHS[i]);
     const std::string a = "a" + std::to_string(i + 1);
     TK(ian_k_pair_loss(t->EH[a], t->EX[a], nullptr, (int64_t)n * (int64_t)cnt, 1, 1, 1, 0.f, 0, t->ws_loss, 1024, 1.f / (N * cnt * 4.f), s + 20 + 2 * i, t->st));
+  }
+  if (t->world > 1) {  // per-rank partial means add up to the global ones
+    int rc = t->comm.allreduce_sum(t->comm.ctx, s, 64, t->st);
+    if (!rc) rc = t->comm.wait_all(t->comm.ctx, t->st);
+    if (rc) return tfail(t, -30, "comm all-reduce of the metrics failed (%d)", rc);
   }
   float v[32];
   THIP(hipMemcpyAsync(v, s, sizeof v, hipMemcpyDeviceToHost, t->st));
@@ -745,10 +1010,10 @@ int metrics(ian_trainer* t, float* out9) {  // all scalar losses of train_IAN.py
 
 int backward(ian_trainer* t, bool gen) {  // gradients of the update rules of train_IAN.py:253-273 (Z_params always)
   const int n = t->n;
-  const float N = (float)n;
+  const float N = (float)t->N;   // loss means are over the GLOBAL batch: summing per-rank gradients gives the 1-GPU gradient
   const ian_train_config& c = t->cfg;
   int rc;
-  t->touched.clear();
+  if ((rc = begin_backward(t, gen ? 0 : 1))) return rc;
   // ---- shared generator-side loss S = adv_gen + recon_weight*pixel + feature_weight*feature ---------------------------------
   for (int i = 0; i < 4; ++i) {  // feature_loss seeds (train_IAN.py:244)
     const float cnt = (float)((32 >> i) * (32 >> i) * ENC_WIDTHS[i]);
@@ -785,7 +1050,7 @@ int regularizers(ian_trainer* t, bool gen) {  // train_IAN.py:211-221: L2 on the
   for (auto& nme : grp.names) {
     const Shape& s = grp.off.at(nme).second;
     if (nme.back() == 'W' && s.d.size() == 4)
-      TK(ian_k_ortho(P(t, nme), G(t, nme), (int)s.d[0], (int)s.d[1], (int)s.d[2], c.ortho, t->tmp_vals, t->st));
+      TK(ian_k_ortho(P(t, nme), G(t, nme), (int)s.d[0], (int)s.d[1], (int)s.d[2], c.ortho, t->ortho_vals, t->st));
   }
   return 0;
 }
@@ -822,6 +1087,8 @@ int ian_trainer_create(const ian_train_config* cfg, ian_trainer** out) {
   ian_trainer* t = new ian_trainer();
   t->cfg = *cfg;
   t->n = cfg->batch;
+  t->N = cfg->batch;
+  memset(&t->comm, 0, sizeof t->comm);
   declare_parameters(t);
   *out = t;
   return 0;
@@ -892,62 +1159,293 @@ int ian_trainer_finalize(ian_trainer* t) {
     THIP(hipMemcpy(t->fc2_perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
     THIP(hipMemcpy(t->fc2_inv, inv.data(), inv.size() * 4, hipMemcpyHostToDevice));
   }
-  t->fc2_bias = dalloc(t, 8192); t->fc2_db = dalloc(t, 8192); t->tmp_big = dalloc(t, 2 * 8192);
+  t->fc2_bias = dalloc(t, 8192); t->fc2_db = dalloc(t, 8192); t->fc2_tmp = dalloc(t, 8192); t->tmp_big = dalloc64(t, 2 * 8192);
   t->ws_stats_cap = (size_t)256 * 2 * 8192;
-  t->ws_stats = dalloc(t, t->ws_stats_cap);
+  t->ws_stats = dalloc64(t, t->ws_stats_cap);
   t->ws_loss = dalloc(t, 1024 * 2); t->scalars = dalloc(t, 64);
   t->mb_W = dalloc(t, (size_t)1024 * 2500); t->mb_dW = dalloc(t, (size_t)1024 * 2500); t->mb_colscale = dalloc(t, 2500);
-  t->tmp_vals = dalloc(t, 2048);
+  t->tmp_vals = dalloc64(t, 2048); t->ortho_vals = dalloc(t, 2048);
   if ((rc = build_layers(t))) return rc;
   enc_alloc(t, t->EX, t->bnEX); enc_alloc(t, t->EH, t->bnEH); enc_alloc(t, t->EG, t->bnEG);
   z_alloc(t);
   dec_alloc(t, t->DZ, t->bnDZ); dec_alloc(t, t->DG, t->bnDG);
   t->zgen = dalloc(t, (size_t)t->n * 128); t->zgen0 = dalloc(t, (size_t)t->n * 128);
   t->xin = dalloc(t, (size_t)t->n * 3 * 4096); t->zin = dalloc(t, (size_t)t->n * 100); t->epsin = dalloc(t, (size_t)t->n * 100);
-  for (float* p : t->allocs)
-    if (!p) return tfail(t, -20, "out of device memory");
+  if (t->oom) return tfail(t, -20, "out of device memory while allocating the training step's buffers (batch %d per GPU)", t->n);
   if (hipStreamCreateWithFlags(&t->st2, hipStreamNonBlocking) != hipSuccess) {
     (void)hipGetLastError();
     t->st2 = nullptr;   // no second stream: weight gradients stay on the compute stream
   }
+  if (t->world > 1) THIP(hipStreamCreateWithFlags(&t->st_comm, hipStreamNonBlocking));
+  if (t->exact && ((t->n & (t->n - 1)) || (t->world & (t->world - 1))))
+    fprintf(stderr, "libian: per-rank batch %d x world %d is not a power of two: the partial-sum tree of the batch statistics associates "
+                    "differently on N ranks and in one process, so the data-parallel step is NOT guaranteed bit-identical to the "
+                    "single-process step (float64 sums: the float32 statistics can differ in the last bit); train_IAN.py's "
+                    "semantics are unaffected\n", t->n, t->world);
   t->dirty = {"enc", "Z", "dec"};
   t->host.clear();
   t->finalized = true;
   return 0;
 }
 
-/* One update of train_IAN.py:309-329.  which: 0 = update_gen, 1 = update_discrim.  x (n,3,64,64) in [-1,1], zrand (n,100),
-   eps (n,100): host or device pointers.  metrics: NULL or 9 HOST floats = discrim_d_loss, gen_recon_loss, gen_sample_loss,
-   discrim_g_loss, discrim_acc, kl_div, pixel_loss, pixel_acc, feature_loss of THIS minibatch before the update (reading them
-   synchronises the stream). */
-int ian_train_step(ian_trainer* t, int32_t which, const float* x, const float* zrand, const float* eps, int32_t n, float* metrics9, void* stream) {
+int ian_trainer_set_comm(ian_trainer* t, const ian_comm_ops* ops, int32_t exact) {
+  if (!t || !ops) return -1;
+  if (t->finalized) return tfail(t, -6, "ian_trainer_set_comm must be called before ian_trainer_finalize (buffer sizes depend on the world size)");
+  if (ops->world < 1 || ops->rank < 0 || ops->rank >= ops->world) return tfail(t, -1, "ian_trainer_set_comm: bad world / rank (%d / %d)", ops->world, ops->rank);
+  if (ops->world > 1 && (!ops->allreduce_sum || !ops->wait_all || !ops->allgather)) return tfail(t, -1, "ian_trainer_set_comm: a callback is NULL");
+  t->comm = *ops;
+  t->world = ops->world;
+  t->rank = ops->rank;
+  t->exact = (exact && ops->world > 1) ? 1 : 0;
+  t->N = t->n * t->world;
+  return 0;
+}
+
+}  // extern "C"
+
+namespace {
+// entry bookkeeping shared by ian_train_step and the piecewise entries: stream hand-over guard + host -> device staging
+int enter(ian_trainer* t, void* stream) {
   if (!t) return -1;
   if (!t->finalized) return tfail(t, -6, "ian_trainer_finalize has not been called");
-  if (!x || !zrand || !eps) return tfail(t, -1, "null pointer passed to ian_train_step");
-  if (n != t->n) return tfail(t, -7, "ian_train_step: batch %d, the trainer was created for %d (batch statistics are per minibatch)", n, t->n);
-  if (which != 0 && which != 1) return tfail(t, -7, "ian_train_step: which must be 0 (update_gen) or 1 (update_discrim)");
-  t->st = (hipStream_t)stream;
-  const std::pair<const float**, std::pair<float*, size_t>> ins[3] = {{&x, {t->xin, (size_t)n * 3 * 4096}}, {&zrand, {t->zin, (size_t)n * 100}},
-                                                                      {&eps, {t->epsin, (size_t)n * 100}}};
+  hipStream_t st = (hipStream_t)stream;
+  if (t->have_last_stream && t->last_stream != st) THIP(hipStreamSynchronize(t->last_stream));  // buffers are shared between calls
+  t->st = st;
+  t->last_stream = st;
+  t->have_last_stream = true;
+  return 0;
+}
+int stage_inputs(ian_trainer* t, const float** x, const float** zrand, const float** eps, int n) {
+  const std::pair<const float**, std::pair<float*, size_t>> ins[3] = {{x, {t->xin, (size_t)n * 3 * 4096}}, {zrand, {t->zin, (size_t)n * 100}},
+                                                                      {eps, {t->epsin, (size_t)n * 100}}};
   for (auto& in : ins)
     if (!is_device_ptr(*in.first)) {
       THIP(hipMemcpyAsync(in.second.first, *in.first, in.second.second * sizeof(float), hipMemcpyHostToDevice, t->st));
       *in.first = in.second.first;
     }
+  return 0;
+}
+int check_step_args(ian_trainer* t, const float* x, const float* zrand, const float* eps, int n, const char* who) {
+  if (!x || !zrand || !eps) return tfail(t, -1, "null pointer passed to %s", who);
+  if (n != t->n) return tfail(t, -7, "%s: batch %d, the trainer was created for %d per GPU (batch statistics are per minibatch)", who, n, t->n);
+  return 0;
+}
+int step_body(ian_trainer* t, bool gen, const float* x, const float* zrand, const float* eps, float* metrics9) {
   int rc;
   if ((rc = forward(t, x, zrand, eps))) return rc;
   if (metrics9 && (rc = metrics(t, metrics9))) return rc;
-  const bool gen = which == 0;
   if ((rc = backward(t, gen))) return rc;
-  if ((rc = join_side_stream(t))) return rc;
+  if ((rc = finish_allreduce(t, gen ? 0 : 1))) return rc;
   if ((rc = regularizers(t, gen))) return rc;
   if ((rc = adam(t, gen ? t->dec : t->enc, gen ? "dec" : "enc"))) return rc;
   return adam(t, t->zp, "Z");
 }
+// error path of any entry that may have issued work on the trainer's own streams: nothing of it may still be running (and
+// writing the shared buffers) when the caller sees the error code
+void quiesce(ian_trainer* t) {
+  const std::string keep = t->err;
+  if (t->st2) (void)hipStreamSynchronize(t->st2);
+  if (t->st_comm) (void)hipStreamSynchronize(t->st_comm);
+  (void)hipStreamSynchronize(t->st);
+  (void)hipGetLastError();
+  t->ev_used = 0;
+  t->buckets = nullptr;
+  t->err = keep;
+}
+}  // namespace
+
+extern "C" {
+
+/* One update of train_IAN.py:309-329.  which: 0 = update_gen, 1 = update_discrim.  x (n,3,64,64) in [-1,1], zrand (n,100),
+   eps (n,100): host or device pointers; n = the PER-RANK batch.  metrics: NULL or 9 HOST floats = discrim_d_loss, gen_recon_loss,
+   gen_sample_loss, discrim_g_loss, discrim_acc, kl_div, pixel_loss, pixel_acc, feature_loss of THIS (global) minibatch before the
+   update (reading them synchronises the stream). */
+int ian_train_step(ian_trainer* t, int32_t which, const float* x, const float* zrand, const float* eps, int32_t n, float* metrics9, void* stream) {
+  int rc;
+  if ((rc = enter(t, stream))) return rc;
+  if ((rc = check_step_args(t, x, zrand, eps, n, "ian_train_step"))) return rc;
+  if (which != 0 && which != 1) return tfail(t, -7, "ian_train_step: which must be 0 (update_gen) or 1 (update_discrim)");
+  t->xhat_override = t->xgen_override = nullptr;
+  if ((rc = stage_inputs(t, &x, &zrand, &eps, n))) return rc;
+  rc = step_body(t, which == 0, x, zrand, eps, metrics9);
+  if (rc) quiesce(t);
+  return rc;
+}
+
+/* ---- the same step in pieces (tests, diagnostics): forward / metrics / backward / all-reduce / regularizers / Adam --------- */
+int ian_trainer_forward(ian_trainer* t, const float* x, const float* zrand, const float* eps, int32_t n, const float* xhat_override,
+                        const float* xgen_override, void* stream) {
+  int rc;
+  if ((rc = enter(t, stream))) return rc;
+  if ((rc = check_step_args(t, x, zrand, eps, n, "ian_trainer_forward"))) return rc;
+  if ((xhat_override && !is_device_ptr(xhat_override)) || (xgen_override && !is_device_ptr(xgen_override)))
+    return tfail(t, -1, "ian_trainer_forward: the override images must be device buffers");
+  if ((rc = stage_inputs(t, &x, &zrand, &eps, n))) return rc;
+  t->xhat_override = xhat_override;
+  t->xgen_override = xgen_override;
+  rc = forward(t, x, zrand, eps);
+  t->xhat_override = t->xgen_override = nullptr;
+  if (rc) quiesce(t);
+  return rc;
+}
+int ian_trainer_metrics(ian_trainer* t, float* metrics9) {
+  if (!t || !t->finalized || !metrics9) return -1;
+  if (!t->X) return tfail(t, -6, "ian_trainer_metrics: no forward pass has run");
+  return metrics(t, metrics9);
+}
+int ian_trainer_backward(ian_trainer* t, int32_t which) {
+  if (!t || !t->finalized || (which != 0 && which != 1)) return -1;
+  if (!t->X) return tfail(t, -6, "ian_trainer_backward: no forward pass has run");
+  const int rc = backward(t, which == 0);
+  if (rc) quiesce(t);
+  return rc;
+}
+int ian_trainer_finish_allreduce(ian_trainer* t, int32_t which) {
+  if (!t || !t->finalized || (which != 0 && which != 1)) return -1;
+  const int rc = finish_allreduce(t, which);
+  if (rc) quiesce(t);
+  return rc;
+}
+int ian_trainer_regularizers(ian_trainer* t, int32_t which) {
+  if (!t || !t->finalized || (which != 0 && which != 1)) return -1;
+  int rc = join_side_stream(t);
+  return rc ? rc : regularizers(t, which == 0);
+}
+int ian_trainer_apply_adam(ian_trainer* t, int32_t which) {
+  if (!t || !t->finalized || (which != 0 && which != 1)) return -1;
+  int rc = join_side_stream(t);
+  if (rc) return rc;
+  if ((rc = adam(t, which == 0 ? t->dec : t->enc, which == 0 ? "dec" : "enc"))) return rc;
+  return adam(t, t->zp, "Z");
+}
+/* One encoder backward sweep of pass 0 = encoder(X), 1 = encoder(X_hat), 2 = encoder(X_gen) with cross-entropy seeds
+   dlogits = w0 (p - onehot(t0)) + w1 (p - onehot(t1)) (t < 0: none); reset != 0 starts a fresh gradient sweep first. */
+int ian_trainer_enc_backward(ian_trainer* t, int32_t pass, int32_t t0, float w0, int32_t t1, float w1, int32_t feature_seeded, int32_t want_w,
+                             int32_t want_dx, int32_t reset) {
+  if (!t || !t->finalized || pass < 0 || pass > 2) return -1;
+  if (reset) {
+    int rc = join_side_stream(t);
+    if (rc) return rc;
+    t->touched.clear();
+    t->evlog.clear();
+    t->buckets = nullptr;
+  }
+  Bufs& E = pass == 0 ? t->EX : (pass == 1 ? t->EH : t->EG);
+  auto& bn = pass == 0 ? t->bnEX : (pass == 1 ? t->bnEH : t->bnEG);
+  int rc = enc_backward(t, E, bn, t0, w0, t1, w1, feature_seeded != 0, want_w != 0, want_dx != 0);
+  if (!rc) rc = join_side_stream(t);
+  if (rc) quiesce(t);
+  return rc;
+}
+/* Device address of an internal buffer: "<pass>.<name>" with pass in EX EH EG ZS DZ DG (activations and gradients, NHWC with the
+   channel stride rounded up to 32; images NCHW), "<pass>.<bn>.<mean|inv_std|scale|shift>" (float32 [C]),
+   "<pass>.<bn>.<sums|bsums>" (float64 [2][C]; numel counts doubles), "scalars", "ws_loss".  Tests / diagnostics only. */
+int ian_trainer_buffer(ian_trainer* t, const char* name, void** ptr, int64_t* numel) {
+  if (!t || !t->finalized || !name || !ptr) return -1;
+  const std::string s = name;
+  if (s == "scalars") { *ptr = t->scalars; if (numel) *numel = 64; return 0; }
+  if (s == "ws_loss") { *ptr = t->ws_loss; if (numel) *numel = 2048; return 0; }
+  const size_t d = s.find('.');
+  if (d == std::string::npos) return tfail(t, -2, "unknown buffer '%s'", name);
+  const std::string ps = s.substr(0, d), rest = s.substr(d + 1);
+  Bufs* B = nullptr;
+  std::map<std::string, BN>* bn = nullptr;
+  if (ps == "EX") { B = &t->EX; bn = &t->bnEX; } else if (ps == "EH") { B = &t->EH; bn = &t->bnEH; } else if (ps == "EG") { B = &t->EG; bn = &t->bnEG; }
+  else if (ps == "ZS") { B = &t->ZS; bn = &t->bnZ; } else if (ps == "DZ") { B = &t->DZ; bn = &t->bnDZ; } else if (ps == "DG") { B = &t->DG; bn = &t->bnDG; }
+  else return tfail(t, -2, "unknown pass in buffer name '%s'", name);
+  auto it = B->find(rest);
+  if (it != B->end()) {
+    *ptr = it->second;
+    if (numel) {
+      auto sz = t->alloc_floats.find(it->second);
+      *numel = sz != t->alloc_floats.end() ? (int64_t)sz->second : -1;
+    }
+    return 0;
+  }
+  const size_t d2 = rest.rfind('.');
+  if (d2 != std::string::npos) {
+    auto bi = bn->find(rest.substr(0, d2));
+    if (bi != bn->end()) {
+      const std::string f = rest.substr(d2 + 1);
+      BN& b = bi->second;
+      void* p = f == "mean" ? (void*)b.mean : f == "inv_std" ? (void*)b.inv_std : f == "scale" ? (void*)b.scale : f == "shift" ? (void*)b.shift
+                : f == "sums" ? (void*)b.sums : f == "bsums" ? (void*)b.bsums : nullptr;
+      if (p) {
+        *ptr = p;
+        if (numel) *numel = (f == "sums" || f == "bsums") ? 2 * b.C : b.C;
+        return 0;
+      }
+    }
+  }
+  return tfail(t, -2, "unknown buffer '%s'", name);
+}
+/* group 0 encoder_params, 1 Z_params, 2 decoder_params, 3 batch-norm running averages: the flat device buffers (reference layouts). */
+int ian_trainer_group(ian_trainer* t, int32_t group, float** p, float** g, float** m, float** v, int64_t* numel) {
+  if (!t || !t->finalized || group < 0 || group > 3) return -1;
+  Group& gr = group == 3 ? t->stats : group_of(t, group);
+  if (p) *p = gr.p;
+  if (g) *g = gr.g;
+  if (m) *m = gr.m;
+  if (v) *v = gr.v;
+  if (numel) *numel = gr.numel;
+  return 0;
+}
+int ian_trainer_param_info(ian_trainer* t, const char* name, int32_t* group, int64_t* offset, int64_t* numel) {
+  if (!t || !name) return -1;
+  auto it = t->where.find(name);
+  if (it == t->where.end()) return tfail(t, -2, "unknown parameter '%s'", name);
+  Group* g = it->second;
+  if (group) *group = g == &t->stats ? 3 : group_index(t, g);
+  if (offset) *offset = g->off.at(name).first;
+  if (numel) *numel = g->off.at(name).second.numel();
+  return 0;
+}
+/* Parameters of `group` were written behind the trainer's back (tests, checkpoint loading): repack before the next forward. */
+int ian_trainer_mark_dirty(ian_trainer* t, int32_t group) {
+  if (!t || group < 0 || group > 2) return -1;
+  t->dirty.insert(group == 0 ? "enc" : (group == 1 ? "Z" : "dec"));
+  return 0;
+}
+/* "exposed_ms_gen" / "exposed_ms_discrim": mean stall of the compute stream on the gradient all-reduce per update of that kind
+   (option measure_exposed = 1; synchronises); "plan_buckets_gen|discrim"; "overlap_log" (entries kept); "world", "rank", "exact",
+   "global_batch". */
+int ian_trainer_stat(ian_trainer* t, const char* key, double* out) {
+  if (!t || !key || !out) return -1;
+  const std::string k = key;
+  if (k == "exposed_ms_gen" || k == "exposed_ms_discrim") {
+    if (t->ex_pending) {
+      float ms = 0.f;
+      if (hipEventSynchronize(t->ex1) == hipSuccess && hipEventElapsedTime(&ms, t->ex0, t->ex1) == hipSuccess) {
+        t->exposed_ms[t->ex_which] += ms;
+        t->exposed_n[t->ex_which] += 1;
+      }
+      (void)hipGetLastError();
+      t->ex_pending = false;
+    }
+    const int w = k == "exposed_ms_gen" ? 0 : 1;
+    *out = t->exposed_n[w] ? t->exposed_ms[w] / t->exposed_n[w] : 0.0;
+  } else if (k == "plan_buckets_gen") *out = t->plans.count(0) ? (double)t->plans[0].size() : 0.0;
+  else if (k == "plan_buckets_discrim") *out = t->plans.count(1) ? (double)t->plans[1].size() : 0.0;
+  else if (k == "overlap_log") *out = (double)t->overlap_log.size();
+  else if (k == "world") *out = t->world;
+  else if (k == "rank") *out = t->rank;
+  else if (k == "exact") *out = t->exact;
+  else if (k == "global_batch") *out = t->N;
+  else return tfail(t, -1, "unknown statistic '%s'", key);
+  return 0;
+}
+/* rec[6] = which, group, first element, bytes, index of the gradient write after which the bucket was handed over, number of
+   gradient writes of that backward sweep (0 while the sweep is still open) */
+int ian_trainer_overlap_log(ian_trainer* t, int32_t index, int64_t* rec) {
+  if (!t || !rec || index < 0 || (size_t)index >= t->overlap_log.size()) return -1;
+  const OverlapRec& r = t->overlap_log[index];
+  rec[0] = r.which; rec[1] = r.group; rec[2] = r.lo; rec[3] = r.bytes; rec[4] = r.issued_at_write; rec[5] = r.writes_in_backward;
+  return 0;
+}
 
 int ian_trainer_autotune(ian_trainer* t, void* stream) {
-  if (!t || !t->finalized) return -1;
-  t->st = (hipStream_t)stream;
+  int rc;
+  if ((rc = enter(t, stream))) return rc;
   const size_t need = (size_t)t->n * 64 * 64 * 128;  // the largest activation of IAN.py (dec_conv4 output)
   std::vector<float> rnd(need);
   unsigned s = 12345u;
@@ -957,10 +1455,18 @@ int ian_trainer_autotune(ian_trainer* t, void* stream) {
   }
   float *a = nullptr, *b = nullptr;
   THIP(hipMalloc((void**)&a, need * sizeof(float)));
-  THIP(hipMalloc((void**)&b, need * sizeof(float)));
-  THIP(hipMemcpy(a, rnd.data(), need * sizeof(float), hipMemcpyHostToDevice));
-  THIP(hipMemcpy(b, rnd.data(), need * sizeof(float), hipMemcpyHostToDevice));
-  int rc = refresh_weights(t);
+  if (hipMalloc((void**)&b, need * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(a);
+    return tfail(t, -20, "out of device memory (autotune operands)");
+  }
+  rc = 0;
+  if (hipMemcpy(a, rnd.data(), need * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(b, rnd.data(), need * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    rc = tfail(t, -20, "hipMemcpy of the autotune operands failed");
+  }
+  if (!rc) rc = refresh_weights(t);
   for (auto& key : t->layer_order) {
     if (rc) break;
     rc = ian_layer_autotune(t->layers[key].l, t->n, a, b, (int64_t)need, t->st);
@@ -981,7 +1487,7 @@ int ian_trainer_read_param(ian_trainer* t, const char* name, int32_t grad, float
   if (grad && !g->g) return tfail(t, -2, "'%s' has no gradient (not trainable)", name);
   const auto& o = g->off.at(name);
   if (o.second.numel() != numel) return tfail(t, -3, "parameter '%s' has %lld elements", name, (long long)o.second.numel());
-  THIP(hipStreamSynchronize(t->st));
+  THIP(hipDeviceSynchronize());   // the compute stream, the weight-gradient stream and the bucket stream
   THIP(hipMemcpy(out, (grad ? g->g : g->p) + o.first, numel * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -993,6 +1499,9 @@ int ian_trainer_set_option(ian_trainer* t, const char* key, double value) {
   else if (k == "head6") t->head6 = value != 0.0;
   else if (k == "overlap_wgrad") t->overlap_wgrad = value != 0.0;
   else if (k == "update_running") t->update_running = value != 0.0;
+  else if (k == "overlap") t->overlap = value != 0.0;                       // gradient buckets handed over during backward
+  else if (k == "bucket_bytes") { t->bucket_bytes = (int64_t)value > 4 ? (int64_t)value : 4; t->plans.clear(); }
+  else if (k == "measure_exposed") { t->measure_exposed = value != 0.0; t->exposed_ms[0] = t->exposed_ms[1] = 0; t->exposed_n[0] = t->exposed_n[1] = 0; t->ex_pending = false; }
   else return tfail(t, -1, "unknown option '%s'", key);
   return 0;
 }
@@ -1010,6 +1519,9 @@ void ian_trainer_destroy(ian_trainer* t) {
   (void)hipDeviceSynchronize();
   for (hipEvent_t e : t->events) (void)hipEventDestroy(e);
   if (t->st2) (void)hipStreamDestroy(t->st2);
+  if (t->st_comm) (void)hipStreamDestroy(t->st_comm);
+  if (t->ex0) (void)hipEventDestroy(t->ex0);
+  if (t->ex1) (void)hipEventDestroy(t->ex1);
   for (auto& kv : t->layers) ian_layer_destroy(kv.second.l);
   for (float* p : t->allocs)
     if (p) (void)hipFree(p);

@@ -39,40 +39,54 @@ static inline int grid_for(long long total, int cap = 8192) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-channel column statistics over NHWC rows.  partial[chunk][2][C]; then tree_sum -> sums[2][C]
+// per-channel column statistics over NHWC rows.  partial[chunk][2][C] DOUBLES; then tree_sum -> sums[2][C] doubles
 //   mode 0: s1 = sum x,  s2 = sum x^2                          (batch-norm forward statistics)
 //   mode 1: g = dA*act'(a): s1 = sum g, s2 = sum g*xhat, xhat = (y-mean)*inv_std   (batch-norm backward: dbeta, dgamma)
 //   mode 2: g = dA*act'(a): s1 = sum g                        (bias gradient)
 // grid = (row chunks, column groups); block shape below.
 //
+// NUMERICS (round 4).  Every float32 element is widened to float64 BEFORE it is squared / multiplied / added, and all partial
+// sums, the tree and the mean / variance arithmetic stay in float64; only mean, inv_std, scale, shift (and the gradients
+// dbeta, dgamma) are rounded to float32, once.  x*x is exact in float64, the sums carry a relative error of ~1e-16 * n, so
+// var = E[x^2] - E[x]^2 is accurate to ~1e-13 * mean^2 -- BETTER conditioned than the float32 two-pass input.var(axes)
+// of Lasagne's BatchNormLayer (oracle/refexec/minilasagne.py:607) that rounds 1e-7 per operation.  Rounds 1-3 formed the same
+// one-pass expression in float32, whose cancellation error scales with mean^2 / var.  The kernels are HBM-bound; the
+// float64 adds (full rate on the gfx950 VALU) are hidden behind the loads.
+//
 // Summation order is a function of the ROW INDEX only, not of how many rows there are: the caller cuts the rows
-// into equal chunks whose size depends on the per-image extent alone (trainer.py: one image or a fixed fraction
+// into equal chunks whose size depends on the per-image extent alone (one image or a fixed fraction
 // of one), a chunk is summed by the block's row lanes in a fixed order, and the chunk partials are combined by tree_sum,
 // a pairwise (binary-counter) tree over the chunk index.  For power-of-two chunk counts
 //     tree(chunks of the whole minibatch) == tree(rank 0's chunks) + tree(rank 1's chunks)   bit for bit,
-// so the data-parallel step (per-rank tree, all-gather, tree over ranks in rank order) computes the SAME float32
-// batch statistics as the single-process step on the whole minibatch (SyncBN).
+// so the data-parallel step (per-rank tree, all-gather, tree over ranks in rank order) computes the SAME
+// batch statistics as the single-process step on the whole minibatch (SyncBN).  For other counts the two trees
+// associate differently: the float64 sums then differ by ~1e-16 relative, i.e. the float32 statistics derived from them are
+// still identical except when a float64 difference straddles a float32 rounding boundary (ian_trainer warns at set-up).
 // ------------------------------------------------------------------------------------------------
 // Block = CL float4 column lanes x (256 / CL) row lanes.  CL = 8 (32 channels = one 128-byte line per row, 32 row lanes) for
 // chunks of >= 64 rows: a 512-row chunk of a 128-channel map is then 4 workgroups instead of one half-idle one, and every
 // thread keeps 4 rows (x up to 3 tensors) of loads in flight; CL = 64 (the whole row across the block) for short chunks.
 // The order inside a chunk -- 4 interleaved accumulators per thread, (0+1)+(2+3), then a halving tree over the row lanes --
 // is fixed by the chunk's row count alone, so the chunk-count independence stated above is unchanged.
+struct d4 { double x, y, z, w; };
+__device__ __forceinline__ void d4_add(d4& a, const d4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 template <int MODE, int CL>
 __global__ __launch_bounds__(256) void colstats_kernel(ColStatsArgs a) {
   constexpr int RL = 256 / CL;
-  __shared__ float4 red[2][256];
+  __shared__ d4 red[2][256];
   const int q = threadIdx.x % CL, rl = threadIdx.x / CL;
   const int c = blockIdx.y * (CL * 4) + q * 4;
   const long long rows_per = (a.rows + gridDim.x - 1) / gridDim.x;
   const long long r0 = (long long)blockIdx.x * rows_per, r1 = min(a.rows, r0 + rows_per);
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 s1[4] = {zero, zero, zero, zero}, s2[4] = {zero, zero, zero, zero};
+  const d4 dzero = {0.0, 0.0, 0.0, 0.0};
+  d4 s1[4] = {dzero, dzero, dzero, dzero}, s2[4] = {dzero, dzero, dzero, dzero};
   if (c < a.C && r0 < r1) {
-    float4 mean = zero, istd = zero;
+    d4 mean = dzero, istd = dzero;
     if (MODE == 1) {
-      mean = *reinterpret_cast<const float4*>(a.mean + c);
-      istd = *reinterpret_cast<const float4*>(a.inv_std + c);
+      const float4 m = *reinterpret_cast<const float4*>(a.mean + c), is = *reinterpret_cast<const float4*>(a.inv_std + c);
+      mean = {m.x, m.y, m.z, m.w};
+      istd = {is.x, is.y, is.z, is.w};
     }
     for (long long r = r0 + rl; r < r1; r += 4 * RL) {
       float4 x[4], av[4], y[4];
@@ -89,21 +103,22 @@ __global__ __launch_bounds__(256) void colstats_kernel(ColStatsArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float4 v = x[j];
-        if (MODE != 0 && a.act) {
+        if (MODE != 0 && a.act) {   // g = dA * act'(a): one float32 product, the value the apply kernel forms as well
           v.x *= t_dact(av[j].x, a.act); v.y *= t_dact(av[j].y, a.act); v.z *= t_dact(av[j].z, a.act); v.w *= t_dact(av[j].w, a.act);
         }
         if (!ok[j]) v = zero;
-        s1[j].x += v.x; s1[j].y += v.y; s1[j].z += v.z; s1[j].w += v.w;
+        const d4 w = {v.x, v.y, v.z, v.w};
+        d4_add(s1[j], w);
         if (MODE == 0) {
-          s2[j].x += v.x * v.x; s2[j].y += v.y * v.y; s2[j].z += v.z * v.z; s2[j].w += v.w * v.w;
+          s2[j].x += w.x * w.x; s2[j].y += w.y * w.y; s2[j].z += w.z * w.z; s2[j].w += w.w * w.w;
         } else if (MODE == 1) {
-          s2[j].x += v.x * (y[j].x - mean.x) * istd.x; s2[j].y += v.y * (y[j].y - mean.y) * istd.y;
-          s2[j].z += v.z * (y[j].z - mean.z) * istd.z; s2[j].w += v.w * (y[j].w - mean.w) * istd.w;
+          s2[j].x += w.x * (((double)y[j].x - mean.x) * istd.x); s2[j].y += w.y * (((double)y[j].y - mean.y) * istd.y);
+          s2[j].z += w.z * (((double)y[j].z - mean.z) * istd.z); s2[j].w += w.w * (((double)y[j].w - mean.w) * istd.w);
         }
       }
     }
   }
-  float4 t1, t2;
+  d4 t1, t2;
   t1.x = (s1[0].x + s1[1].x) + (s1[2].x + s1[3].x); t1.y = (s1[0].y + s1[1].y) + (s1[2].y + s1[3].y);
   t1.z = (s1[0].z + s1[1].z) + (s1[2].z + s1[3].z); t1.w = (s1[0].w + s1[1].w) + (s1[2].w + s1[3].w);
   t2.x = (s2[0].x + s2[1].x) + (s2[2].x + s2[3].x); t2.y = (s2[0].y + s2[1].y) + (s2[2].y + s2[3].y);
@@ -114,31 +129,31 @@ __global__ __launch_bounds__(256) void colstats_kernel(ColStatsArgs a) {
 #pragma unroll
   for (int w = RL / 2; w >= 1; w >>= 1) {   // halving tree over the row lanes: lane l takes l + w
     if (rl < w) {
-      const float4 u = red[0][threadIdx.x + w * CL], v = red[1][threadIdx.x + w * CL];
-      float4 m = red[0][threadIdx.x], n = red[1][threadIdx.x];
-      m.x += u.x; m.y += u.y; m.z += u.z; m.w += u.w;
-      n.x += v.x; n.y += v.y; n.z += v.z; n.w += v.w;
+      d4 m = red[0][threadIdx.x], n = red[1][threadIdx.x];
+      d4_add(m, red[0][threadIdx.x + w * CL]);
+      d4_add(n, red[1][threadIdx.x + w * CL]);
       red[0][threadIdx.x] = m;
       red[1][threadIdx.x] = n;
     }
     __syncthreads();
   }
   if (rl == 0 && c < a.C) {
-    float* p = a.partial + (size_t)blockIdx.x * 2 * a.C;
-    *reinterpret_cast<float4*>(p + c) = red[0][threadIdx.x];
-    *reinterpret_cast<float4*>(p + a.C + c) = red[1][threadIdx.x];
+    double* p = a.partial + (size_t)blockIdx.x * 2 * a.C;
+    const d4 u = red[0][threadIdx.x], v = red[1][threadIdx.x];
+    p[c] = u.x; p[c + 1] = u.y; p[c + 2] = u.z; p[c + 3] = u.w;
+    p[a.C + c] = v.x; p[a.C + c + 1] = v.y; p[a.C + c + 2] = v.z; p[a.C + c + 3] = v.w;
   }
 }
 
 // Pairwise tree over `count` values p[0], p[stride], ...: T(lo,hi) = T(lo,lo+m) + T(lo+m,hi) with m the largest power
 // of two below hi-lo -- evaluated left to right with a binary counter of partial sums (no recursion, registers only).
 constexpr int TS_LEVELS = 16;
-__device__ __forceinline__ float tree_sum_seq(const float* __restrict__ p, size_t stride, int count) {
-  float acc[TS_LEVELS];
+__device__ __forceinline__ double tree_sum_seq(const double* __restrict__ p, size_t stride, int count) {
+  double acc[TS_LEVELS];
 #pragma unroll
-  for (int l = 0; l < TS_LEVELS; ++l) acc[l] = 0.f;
+  for (int l = 0; l < TS_LEVELS; ++l) acc[l] = 0.0;
   for (int k = 0; k < count; ++k) {
-    float v = p[(size_t)k * stride];
+    double v = p[(size_t)k * stride];
     bool placed = false;
 #pragma unroll
     for (int l = 0; l < TS_LEVELS; ++l) {
@@ -148,7 +163,7 @@ __device__ __forceinline__ float tree_sum_seq(const float* __restrict__ p, size_
       }
     }
   }
-  float r = 0.f;
+  double r = 0.0;
   bool have = false;
 #pragma unroll
   for (int l = 0; l < TS_LEVELS; ++l)
@@ -161,12 +176,12 @@ __device__ __forceinline__ float tree_sum_seq(const float* __restrict__ p, size_
 // out[i] = tree over k of partial[k*width + i].  Block = 16 columns x 16 lanes; for a power-of-two count each lane
 // takes a contiguous 1/16th (its own subtree) and the lanes meet pairwise in LDS, which is the same tree.
 // tree_column: every thread of the block calls it; the column's total is in red[col] afterwards.
-__device__ __forceinline__ void tree_column(const float* __restrict__ partial, int count, int width, int i, bool valid,
-                                            float* red) {
+__device__ __forceinline__ void tree_column(const double* __restrict__ partial, int count, int width, int i, bool valid,
+                                            double* red) {
   const int lane = threadIdx.x >> 4;
   const bool pow2 = (count & (count - 1)) == 0;
   const int L = pow2 ? min(16, count) : 1;   // lanes in use
-  float s = 0.f;
+  double s = 0.0;
   if (valid && lane < L) {
     const int per = count / L;
     s = tree_sum_seq(partial + (size_t)lane * per * width + i, (size_t)width, per);
@@ -178,15 +193,15 @@ __device__ __forceinline__ void tree_column(const float* __restrict__ partial, i
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(256) void tree_sum_kernel(const float* __restrict__ partial, int count, int width,
-                                                       float* __restrict__ out) {
-  __shared__ float red[256];
+__global__ __launch_bounds__(256) void tree_sum_kernel(const double* __restrict__ partial, int count, int width,
+                                                       double* __restrict__ out) {
+  __shared__ double red[256];
   const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + col;
   tree_column(partial, count, width, i, i < width, red);
   if (lane == 0 && i < width) out[i] = red[col];
 }
-hipError_t launch_tree_sum(const float* partial, int count, int width, float* out, hipStream_t s) {
+hipError_t launch_tree_sum(const double* partial, int count, int width, double* out, hipStream_t s) {
   if (count <= 0 || width <= 0 || count >= (1 << TS_LEVELS)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(tree_sum_kernel, dim3((width + 15) / 16), dim3(256), 0, s, partial, count, width, out);
   return hipGetLastError();
@@ -194,14 +209,17 @@ hipError_t launch_tree_sum(const float* partial, int count, int width, float* ou
 
 // batch statistics -> folded affine (App. B.3): mean, biased variance, inv_std = 1/sqrt(var+eps).  One statement of the
 // arithmetic, contraction off, for bn_make_affine_kernel and bn_finish_kernel: the fused single-process statistics and the
-// two-stage data-parallel ones (all-gather between the tree and this) must agree bit for bit.
-__device__ __forceinline__ void bn_affine_math(float s1, float s2, float count, float eps, float gamma, float beta,
+// two-stage data-parallel ones (all-gather between the tree and this) must agree bit for bit.  Mean and variance are formed in
+// float64 from the float64 sums and rounded to float32 once; scale / shift are float32 products of the rounded values (what
+// the affine apply kernel and the backward read).
+__device__ __forceinline__ void bn_affine_math(double s1, double s2, double count, float eps, float gamma, float beta,
                                                float& m, float& is, float& sc, float& sh) {
 #pragma clang fp contract(off)
-  m = s1 / count;
-  float var = s2 / count - m * m;
-  var = var > 0.f ? var : 0.f;
-  is = 1.f / sqrtf(var + eps);
+  const double md = s1 / count;
+  double var = s2 / count - md * md;
+  var = var > 0.0 ? var : 0.0;
+  m = (float)md;
+  is = (float)(1.0 / sqrt(var + (double)eps));
   sc = gamma * is;
   sh = beta - m * sc;
 }
@@ -216,10 +234,10 @@ __device__ __forceinline__ float running_math(float r, float batch, float keep, 
 // columns c and C + c of partial[chunk][2][C], bn_make_affine's arithmetic, and the running averages of the pass that owns
 // them.  Block = 8 channels x {s1, s2} x 16 lanes.
 struct BnFinishArgs {
-  const float* partial;
+  const double* partial;
   const float* gamma;
   const float* beta;
-  float* sums;
+  double* sums;
   float* mean;
   float* inv_std;
   float* scale;
@@ -230,16 +248,16 @@ struct BnFinishArgs {
   int count, C;
 };
 __global__ __launch_bounds__(256) void bn_finish_kernel(BnFinishArgs a) {
-  __shared__ float red[256];
+  __shared__ double red[256];
   const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
   const int ch = blockIdx.x * 8 + (col & 7);
   tree_column(a.partial, a.count, 2 * a.C, (col >> 3) * a.C + ch, ch < a.C, red);
   if (lane == 0 && col < 8 && ch < a.C) {
-    const float s1 = red[col], s2 = red[col + 8];
+    const double s1 = red[col], s2 = red[col + 8];
     a.sums[ch] = s1;
     a.sums[a.C + ch] = s2;
     float m, is, sc, sh;
-    bn_affine_math(s1, s2, a.n, a.eps, a.gamma[ch], a.beta[ch], m, is, sc, sh);
+    bn_affine_math(s1, s2, (double)a.n, a.eps, a.gamma[ch], a.beta[ch], m, is, sc, sh);
     a.mean[ch] = m;
     a.inv_std[ch] = is;
     a.scale[ch] = sc;
@@ -251,25 +269,25 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(BnFinishArgs a) {
   }
 }
 // second stage of the batch-norm BACKWARD statistics: the tree, then dbeta (+)= s1 and dgamma (+)= s2 (the two gradient
-// accumulations that used to be ian_k_axpy launches)
-__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restrict__ partial, int count, int C,
-                                                            float* __restrict__ sums, float* __restrict__ gbeta, int acc_beta,
+// accumulations that used to be ian_k_axpy launches); the float64 sums are rounded to float32 once, here
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const double* __restrict__ partial, int count, int C,
+                                                            double* __restrict__ sums, float* __restrict__ gbeta, int acc_beta,
                                                             float* __restrict__ ggamma, int acc_gamma) {
-  __shared__ float red[256];
+  __shared__ double red[256];
   const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + col;
   tree_column(partial, count, 2 * C, i, i < 2 * C, red);
   if (lane == 0 && i < 2 * C) {
-    const float v = red[col];
+    const double v = red[col];
     sums[i] = v;
     if (gbeta) {
-      if (i < C) gbeta[i] = (acc_beta ? gbeta[i] : 0.f) + v;
-      else ggamma[i - C] = (acc_gamma ? ggamma[i - C] : 0.f) + v;
+      if (i < C) gbeta[i] = (acc_beta ? gbeta[i] : 0.f) + (float)v;
+      else ggamma[i - C] = (acc_gamma ? ggamma[i - C] : 0.f) + (float)v;
     }
   }
 }
 static void launch_colstats_stage1(const ColStatsArgs& a, int nchunks, hipStream_t s);
-hipError_t launch_bn_stats_affine(const ColStatsArgs& a, int nchunks, float* sums, float count, float eps, const float* gamma,
+hipError_t launch_bn_stats_affine(const ColStatsArgs& a, int nchunks, double* sums, float count, float eps, const float* gamma,
                                   const float* beta, float* mean, float* inv_std, float* scale, float* shift, float* run_mean,
                                   float* run_inv_std, float keep, float alpha, hipStream_t s) {
   if ((a.C & 3) || a.mode != 0 || nchunks <= 0 || nchunks >= (1 << TS_LEVELS)) return hipErrorInvalidValue;
@@ -281,7 +299,7 @@ hipError_t launch_bn_stats_affine(const ColStatsArgs& a, int nchunks, float* sum
   hipLaunchKernelGGL(bn_finish_kernel, dim3((a.C + 7) / 8), dim3(256), 0, s, f);
   return hipGetLastError();
 }
-hipError_t launch_bn_bwd_stats(const ColStatsArgs& a, int nchunks, float* sums, float* gbeta, int acc_beta, float* ggamma,
+hipError_t launch_bn_bwd_stats(const ColStatsArgs& a, int nchunks, double* sums, float* gbeta, int acc_beta, float* ggamma,
                                int acc_gamma, hipStream_t s) {
   if ((a.C & 3) || a.mode != 1 || nchunks <= 0 || nchunks >= (1 << TS_LEVELS)) return hipErrorInvalidValue;
   launch_colstats_stage1(a, nchunks, s);
@@ -303,14 +321,14 @@ static void launch_colstats_stage1(const ColStatsArgs& a, int nchunks, hipStream
   else IAN_COLSTATS(2);
 #undef IAN_COLSTATS
 }
-hipError_t launch_colstats(const ColStatsArgs& a, int nchunks, float* sums, hipStream_t s) {
+hipError_t launch_colstats(const ColStatsArgs& a, int nchunks, double* sums, hipStream_t s) {
   if (a.C & 3) return hipErrorInvalidValue;
   launch_colstats_stage1(a, nchunks, s);
   return launch_tree_sum(a.partial, nchunks, 2 * a.C, sums, s);
 }
 
 // batch statistics -> folded affine (App. B.3): mean, biased variance, inv_std = 1/sqrt(var+eps)
-__global__ __launch_bounds__(256) void bn_make_affine_kernel(const float* __restrict__ sums, float count, float eps,
+__global__ __launch_bounds__(256) void bn_make_affine_kernel(const double* __restrict__ sums, float count, float eps,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int C,
                                                              float* __restrict__ mean, float* __restrict__ inv_std,
@@ -318,13 +336,13 @@ __global__ __launch_bounds__(256) void bn_make_affine_kernel(const float* __rest
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   float m, is, sc, sh;
-  bn_affine_math(sums[c], sums[C + c], count, eps, gamma[c], beta[c], m, is, sc, sh);
+  bn_affine_math(sums[c], sums[C + c], (double)count, eps, gamma[c], beta[c], m, is, sc, sh);
   mean[c] = m;
   inv_std[c] = is;
   scale[c] = sc;
   shift[c] = sh;
 }
-hipError_t launch_bn_make_affine(const float* sums, float count, float eps, const float* gamma, const float* beta,
+hipError_t launch_bn_make_affine(const double* sums, float count, float eps, const float* gamma, const float* beta,
                                  int C, float* mean, float* inv_std, float* scale, float* shift, hipStream_t s) {
   hipLaunchKernelGGL(bn_make_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, count, eps, gamma, beta, C, mean,
                      inv_std, scale, shift);
@@ -337,7 +355,7 @@ hipError_t launch_bn_make_affine(const float* sums, float count, float eps, cons
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   const int c4n = a.C >> 2;
   const long long total = a.rows * c4n;
-  const float invn = 1.f / a.count;
+  const double invn = 1.0 / (double)a.count;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / c4n;
     const int c = (int)(i % c4n) * 4;
@@ -351,11 +369,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
       const float4 y = *reinterpret_cast<const float4*>(a.y + off);
       const float4 mean = *reinterpret_cast<const float4*>(a.mean + c), istd = *reinterpret_cast<const float4*>(a.inv_std + c);
       const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
-      const float4 s1 = *reinterpret_cast<const float4*>(a.sums + c), s2 = *reinterpret_cast<const float4*>(a.sums + a.C + c);
-      g.x = sc.x * (g.x - s1.x * invn - (y.x - mean.x) * istd.x * s2.x * invn);
-      g.y = sc.y * (g.y - s1.y * invn - (y.y - mean.y) * istd.y * s2.y * invn);
-      g.z = sc.z * (g.z - s1.z * invn - (y.z - mean.z) * istd.z * s2.z * invn);
-      g.w = sc.w * (g.w - s1.w * invn - (y.w - mean.w) * istd.w * s2.w * invn);
+      // mean(g), mean(g*xhat): float64 sums / N rounded to float32 once (8 doubles per thread per row group: L1-resident)
+      const double* s1 = a.sums + c;
+      const double* s2 = a.sums + a.C + c;
+      const float4 m1 = make_float4((float)(s1[0] * invn), (float)(s1[1] * invn), (float)(s1[2] * invn), (float)(s1[3] * invn));
+      const float4 m2 = make_float4((float)(s2[0] * invn), (float)(s2[1] * invn), (float)(s2[2] * invn), (float)(s2[3] * invn));
+      g.x = sc.x * (g.x - m1.x - (y.x - mean.x) * istd.x * m2.x);
+      g.y = sc.y * (g.y - m1.y - (y.y - mean.y) * istd.y * m2.y);
+      g.z = sc.z * (g.z - m1.z - (y.z - mean.z) * istd.z * m2.z);
+      g.w = sc.w * (g.w - m1.w - (y.w - mean.w) * istd.w * m2.w);
     }
     *reinterpret_cast<float4*>(a.dy + off) = g;
   }
@@ -374,6 +396,16 @@ __global__ __launch_bounds__(256) void axpy_kernel(float alpha, const float* __r
 }
 hipError_t launch_axpy(float alpha, const float* x, float* y, long long n, int accumulate, hipStream_t s) {
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, s, alpha, x, y, n, accumulate);
+  return hipGetLastError();
+}
+// y (+)= (float)(alpha * x), x float64: the float64 column sums of colstats -> a float32 gradient (rounded once)
+__global__ __launch_bounds__(256) void axpy_f64_kernel(double alpha, const double* __restrict__ x, float* __restrict__ y,
+                                                       long long n, int accumulate) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    y[i] = (accumulate ? y[i] : 0.f) + (float)(alpha * x[i]);
+}
+hipError_t launch_axpy_f64(double alpha, const double* x, float* y, long long n, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(axpy_f64_kernel, dim3(grid_for(n)), dim3(256), 0, s, alpha, x, y, n, accumulate);
   return hipGetLastError();
 }
 

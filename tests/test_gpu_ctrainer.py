@@ -1,8 +1,7 @@
-"""ian_train_step (include/ian_train.h, csrc/ian_trainer.cpp): the whole train_IAN.py update behind one C entry.  It issues
-the same ian_layer_* / ian_k_* launches as trainer.Trainer in the same order, so it must reproduce that step BIT FOR BIT
-(metrics, every gradient, every parameter and running average after the update); trainer.Trainer in turn is held against the
-float64 twin and the reference-executed fixtures by tests/test_gpu_train*.py and tests/test_gpu_reference_pinned.py.  The
-reference-executed metrics are checked here directly as well."""
+"""ian_train_step (include/ian_train.h, csrc/ian_trainer.cpp): the whole train_IAN.py update behind one C entry, the ONLY
+sequencer of the step since round 4 (trainer.Trainer is its thin ctypes caller).  The one-call entry is held bit for bit to
+the same sequencer driven piece by piece -- the form tests/test_gpu_train*.py and tests/test_gpu_reference_pinned.py hold
+against the float64 twin and the reference-executed fixtures -- and to the reference-executed metrics directly."""
 import os
 
 import numpy as np
@@ -18,7 +17,11 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 B = 4
 
 
-def test_c_step_is_bitwise_the_python_sequenced_step():
+def test_one_call_step_is_bitwise_the_piecewise_step():
+    """ian_train_step (one call, HOST buffers, as a C caller would pass them) against the same sequencer driven piece by piece
+    (ian_trainer_forward / metrics / backward / finish_allreduce / regularizers / apply_adam, DEVICE tensors): the parity tests
+    of tests/test_gpu_train*.py and test_gpu_reference_pinned.py drive the pieces, the product calls the one entry -- they must
+    be the same arithmetic bit for bit (metrics, every gradient, every parameter and running average after four updates)."""
     import torch
     from neural_photo_editor_amd.ctrainer import CTrainer, METRICS
     from neural_photo_editor_amd.trainer import Trainer
@@ -28,20 +31,38 @@ def test_c_step_is_bitwise_the_python_sequenced_step():
     for it, which in enumerate(("gen", "discrim", "gen", "discrim")):
         X, Z = S.make_images(B, seed=60 + it), S.make_latents(B, seed=70 + it)
         eps = np.random.RandomState(80 + it).randn(B, 100).astype(np.float32)
-        mc = ct.step(which, X, Z, eps)                         # host buffers, as a C caller would pass them
-        mp = tr.step(which, dev(X), dev(Z), dev(eps))
+        mc = ct.step(which, X, Z, eps)
+        tr.forward(dev(X), dev(Z), dev(eps))
+        mp = tr.metrics()
+        tr.backward(which)
+        tr._finish_allreduce(which)
+        tr._regularizers(which)
         for k in METRICS:
-            assert mc[k] == np.float32(mp[k]), (it, k, mc[k], mp[k])
+            assert mc[k] == mp[k], (it, k, mc[k], mp[k])
         for gname in (("dec" if which == "gen" else "enc"), "Z"):
             for name, g in tr.grads_numpy(gname).items():
                 assert np.array_equal(ct.read(name, grad=True), g), (it, name)
+        tr._apply_adam(which)
     for name, v in tr.state_dict().items():
         if not name.startswith("l_IAF_"):
             assert np.array_equal(ct.read(name), v), name
-    assert ct.adam_steps() == (2, 4, 2)                        # encoder_params, Z_params (both updates), decoder_params
+    assert ct.adam_steps() == (2, 4, 2) == tr.adam_steps()     # encoder_params, Z_params (both updates), decoder_params
     moved = np.abs(ct.read("dec_conv1.W") - P["dec_conv1.W"]).mean()
     assert moved > 0.2 * tr.lr
     assert np.abs(ct.read("bnorm2.mean") - P["bnorm2.mean"]).max() > 1e-3     # running averages follow the real-data pass
+
+
+def test_step_rejects_mistyped_buffers():
+    """a non-contiguous / float64 / mis-shaped tensor must fail loudly, not train on garbage."""
+    import torch
+    from neural_photo_editor_amd.trainer import Trainer, IanTrainError
+    P = S.make_train_params(S.make_params("IAN", 1))
+    tr = Trainer(CFG, P, batch=B)
+    X, Z = torch.zeros(B, 3, 64, 64, device="cuda"), torch.zeros(B, 100, device="cuda")
+    for bad in ((X.double(), Z, Z), (X.permute(0, 1, 3, 2), Z, Z), (X, Z[:, :50], Z), (X, Z, torch.zeros(B, 128, device="cuda")[:, :100]),
+                (X[:2], Z[:2], Z[:2])):
+        with pytest.raises(IanTrainError):
+            tr.step("gen", *bad)
 
 
 def test_c_step_metrics_vs_reference_train_IAN_and_device_pointers():

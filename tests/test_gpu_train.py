@@ -103,8 +103,7 @@ def test_encoder_passes_backward_sharp(setup):
         p = tw.discriminator(g[3])
         feats.append((xin, g, p))
         ref = torch.autograd.grad((-torch.log(p[:, t])).mean(), enc, retain_graph=True)
-        tr.touched = set()
-        tr.enc_backward(E, (t, 1.0 / N, -1, 0.0), False, True, False)
+        tr.enc_backward(E, (t, 1.0 / N, -1, 0.0), False, True, False, reset=True)
         got = tr.grads_numpy("enc")
         for n, r in zip(ENC_PARAMS, ref):
             assert rel(got[n], r.numpy()) < 2e-4, (t, n)
@@ -117,8 +116,7 @@ def test_encoder_passes_backward_sharp(setup):
         cnt = (32 >> i) ** 2 * w
         tr.k.pair_loss(tr.EH["a%d" % (i + 1)], tr.EX["a%d" % (i + 1)], tr.EH["da%d" % (i + 1)], B * cnt, 1, 1, 1, 1.0 / (4.0 * N * cnt), 0,
                        tr.ws_loss, 1024, 0.0, tr.scalars[40:42])
-    tr.touched = set()
-    tr.enc_backward(tr.EH, (0, 1.0 / N, -1, 0.0), True, False, True)
+    tr.enc_backward(tr.EH, (0, 1.0 / N, -1, 0.0), True, False, True, reset=True)
     got = tr.EH["dx"].cpu().numpy()[..., :3].transpose(0, 3, 1, 2)
     assert rel(got, gx.numpy()) < 2e-4
 

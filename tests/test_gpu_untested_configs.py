@@ -151,7 +151,7 @@ def test_batch_norm_at_the_benchmarked_batch(env, rows_per_image, C, act):
     ad = torch.zeros_like(yd)
     bn = T.BN(torch, C, "cuda")
     nch = n * max(1, rows_per_image // 512)
-    ws = torch.zeros(nch * 2 * C, device="cuda")
+    ws = torch.zeros(nch * 2 * C, device="cuda", dtype=torch.float64)
     k.colstats(0, yd, None, None, None, None, rows, C, stride, 0, ws, nch, bn.sums)
     k.bn_make_affine(bn.sums, float(rows), 1e-4, torch.from_numpy(gamma).cuda(), torch.from_numpy(beta).cuda(), C, bn.mean, bn.inv_std, bn.scale, bn.shift)
     k.affine(yd, ad, bn.scale, bn.shift, rows, C, stride, act)
@@ -229,8 +229,7 @@ def test_encoder_passes_at_the_benchmarked_batch():
         g = tw.encoder(torch.tensor(img, dtype=torch.float64))
         p = tw.discriminator(g[3])
         ref = torch.autograd.grad((-torch.log(p[:, t])).mean(), enc)
-        tr.touched = set()
-        tr.enc_backward(E, (t, 1.0 / tr.N, -1, 0.0), False, True, False)
+        tr.enc_backward(E, (t, 1.0 / tr.N, -1, 0.0), False, True, False, reset=True)
         got = tr.grads_numpy("enc")
         errs = sorted(((rel(got[n], r.numpy()), n) for n, r in zip(ENC_PARAMS, ref)), reverse=True)
         out["target%d" % t] = {"median": float(np.median([e for e, _ in errs])), "worst": errs[:4]}
@@ -329,20 +328,20 @@ class _LocalComm:
     """A 2-rank communicator whose collectives are identities: what rank 0 computes BEFORE the gradient sum."""
     active, world, rank, group, bucket_bytes = True, 2, 0, None, 16 << 20
 
-    def all_reduce_sum(self, t, async_op=False):
-        class _W:
-            def wait(self):
-                pass
-        return _W()
+    def ops(self, torch):
+        from neural_photo_editor_amd.trainer import build_ops
+        self.errors, self.calls = [], {"allreduce": 0, "wait_all": 0}
 
-    def all_reduce_sum_ordered(self, t, k):
-        raise AssertionError("exact=False must not all-reduce batch statistics")
+        def allreduce(buf, count, stream):
+            self.calls["allreduce"] += 1           # identity: the gradient stays the rank's own contribution
 
-    def all_gather_rows(self, local, out):
-        raise AssertionError("exact=False must not all-gather MinibatchLayer activations")
+        def wait_all(stream):
+            self.calls["wait_all"] += 1
 
-    def all_reduce_buckets(self, flat, async_op=False):
-        return []
+        def allgather(src, dst, count, stream):
+            raise AssertionError("exact=False must neither all-gather batch statistics nor MinibatchLayer activations")
+
+        return build_ops(self.world, self.rank, allreduce, wait_all, allgather, self.errors)
 
     def barrier(self):
         pass
@@ -367,6 +366,8 @@ def test_local_statistics_mode(which):
         tr.forward(dev(X), dev(Z), dev(eps))
         tr.backward(which)
         tr._finish_allreduce(which)
+    torch.cuda.synchronize()
+    assert local.comm.calls["allreduce"] == local.plan_size(which) > 0 and local.comm.calls["wait_all"] == 1 and not local.comm.errors
     assert torch.equal(single.DZ["xhat"], local.DZ["xhat"]) and torch.equal(single.EG["p"], local.EG["p"])
     for g in (("dec" if which == "gen" else "enc"), "Z"):
         a, b = single.groups[g].g, local.groups[g].g
