@@ -36,6 +36,8 @@ FLOP_PER_RECON = {"IAN_simple": 2.592e9, "IAN": 8.463e9}  # ALGO
 FLOP_EXECUTED = {"IAN_simple": 2.592e9, "IAN": 7.907e9}
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6290 GB/s measured achievable)
 EDIT_STEP_BYTES = 232e6         # one brush event = 2 decoder forwards + 1 backward-data, batch 1, uncached weights
+EDIT_STEP_BYTES_EXECUTED = 151e6  # what a brush event executes with the decoder-forward cache: 1 forward (77 MB) + 1 backward-data (74 MB)
+B1_RECON_BYTES = 214e6          # IAN_simple encoder B=1 137 MB + decoder B=1 77 MB (weights dominate), floors 17.2 + 9.7 us
 # train_IAN.py step, FLOP per image: E = encoder + discriminator forward, D = decoder forward (executed);
 # data-gradient and weight-gradient passes each cost one forward.  Both updates run 3 E + 2 D forward (train_IAN.py:116,140,149).
 #   update_gen     backward: decoder x2 passes (data + weight) = 4 D, encoder data-gradient for X_hat and X_gen = 2 E
@@ -133,17 +135,15 @@ def pmc_traffic(arch, B):
 
 
 def train_step_bench(batch, rank, world, iters=3):
-    """ms per update_gen / update_discrim (train_IAN.py:309-329) of the full IAN at `batch` images per GPU."""
+    """ms per update_gen / update_discrim (train_IAN.py:309-329) of the full IAN at `batch` images per GPU.  The SAME entry
+    at every world size: ian_train_step (csrc/ian_trainer.cpp); at N > 1 its collectives arrive through the ian_comm_ops
+    table filled from torch.distributed (RCCL), SyncBN + MinibatchLayer all-gather on ("exact")."""
     import torch
     from neural_photo_editor_amd.trainer import Trainer, Comm
     from neural_photo_editor_amd import synthetic as O
     P = O.make_train_params(O.make_params("IAN", 1))
     cfg_path = os.path.join(ROOT, "neural_photo_editor_amd", "configs", "IAN.py")
-    if world == 1:
-        from neural_photo_editor_amd.ctrainer import CTrainer
-        tr = CTrainer(cfg_path, P, batch)              # one GPU: the step is ONE C call (ian_train_step, csrc/ian_trainer.cpp)
-    else:
-        tr = Trainer(cfg_path, P, batch=batch, comm=Comm(), exact=True)   # data parallel: trainer.py sequences the same launches + RCCL
+    tr = Trainer(cfg_path, P, batch=batch, comm=Comm(), exact=True)
     rs = np.random.RandomState(50 + rank)
     X = torch.from_numpy(O.make_images(batch, seed=200 + rank)).cuda()
     Z = torch.from_numpy(rs.randn(batch, 100).astype(np.float32)).cuda()
@@ -158,14 +158,14 @@ def train_step_bench(batch, rank, world, iters=3):
         tr.step(which, X, Z, eps, return_metrics=False)          # second warm-up: first step with the overlapped all-reduce
         torch.cuda.synchronize()
         if world > 1:
-            tr._exposed_events.clear()
+            tr.measure_exposed = True                            # resets the counters: only the timed steps are averaged
         t = time.perf_counter()
         for _ in range(iters):
             tr.step(which, X, Z, eps, return_metrics=False)
         torch.cuda.synchronize()
         out["update_%s_ms" % which] = (time.perf_counter() - t) / iters * 1e3
         if world > 1:   # compute-stream stall on the gradient all-reduce (what backward did not hide), mean per update of this kind
-            out.setdefault("allreduce_exposed_ms", {}).update(tr.allreduce_exposed_ms())
+            out.setdefault("allreduce_exposed_ms", {})[which] = tr.allreduce_exposed_ms()[which]
     pair = out["update_gen_ms"] + out["update_discrim_ms"]
     flops = batch * (TRAIN_FLOP_PER_IMAGE["gen"] + TRAIN_FLOP_PER_IMAGE["discrim"])
     ach = flops / (pair * 1e-3) / 1e12
@@ -177,11 +177,100 @@ def train_step_bench(batch, rank, world, iters=3):
                        "basis": "executed FLOP of the GEMM-shaped passes (5 E + 6 D per image for update_gen, 10 E + 3 D for update_discrim; "
                                 "E = 1.316 G encoder+discriminator forward, D = 6.596 G decoder forward) over the measured update time"}
     out.update({"images_per_s": 2 * batch * world / (pair * 1e-3), "per_gpu_batch": batch, "global_batch": batch * world,
-                "parallelism": "dp%d, %s all-reduce of flat gradient groups, SyncBN statistics + MinibatchLayer all-gather (exact)"
-                               % (world, "RCCL" if os.environ.get("IAN_BENCH_BACKEND", "nccl") == "nccl" else os.environ["IAN_BENCH_BACKEND"] + " (test backend)"),
-                "entry": "ian_train_step (C, csrc/ian_trainer.cpp)" if world == 1 else "trainer.Trainer.step (Python-sequenced ian_layer_* / ian_k_* launches + torch.distributed)",
+                "parallelism": ("single GPU" if world == 1 else
+                                "dp%d, %s all-reduce of flat gradient groups in 16 MB buckets overlapped with backward, SyncBN statistics + "
+                                "MinibatchLayer all-gather (exact)"
+                                % (world, "RCCL" if os.environ.get("IAN_BENCH_BACKEND", "nccl") == "nccl" else os.environ["IAN_BENCH_BACKEND"] + " (test backend)")),
+                "entry": "ian_train_step (C, csrc/ian_trainer.cpp)%s" % ("" if world == 1 else "; collectives through ian_comm_ops <- torch.distributed"),
                 "note": "one update_gen + one update_discrim (strict alternation, train_IAN.py:497-504) over synthetic data"})
+    tr.close()
     return out
+
+
+def guarded_train_leg(args, rank, world, result, backend):
+    """The training-step leg must never take the reconstruction headline down: a rank that fails before or inside a
+    collective would leave the others blocked until the process-group timeout.  (1) every rank reports whether its set-up worked
+    and all skip together if one did not; (2) a watchdog prints the stashed headline line with train_step = timeout and ends the
+    process if the leg has not returned within --train-timeout seconds."""
+    import threading
+    import torch
+    import torch.distributed as dist
+    done = threading.Event()
+
+    def bail():
+        if done.is_set():
+            return
+        if rank == 0 and result is not None:
+            result["train_step"] = {"error": "timeout: the data-parallel training leg did not finish within %d s (headline unaffected)" % args.train_timeout}
+            _finalize_secondary(result)
+            print(json.dumps(result), flush=True)
+        os._exit(0 if rank == 0 else 3)
+
+    timer = None
+    if world > 1:
+        timer = threading.Timer(args.train_timeout, bail)
+        timer.daemon = True
+        timer.start()
+    try:
+        ok = 1
+        try:
+            from neural_photo_editor_amd.trainer import Trainer  # noqa: F401  (import / library errors surface on every rank alike)
+            free, _ = torch.cuda.mem_get_info()
+            if free < (12 << 30):
+                raise RuntimeError("only %.1f GB of HBM free" % (free / 2 ** 30))
+        except Exception as exc:
+            ok, why = 0, "%s: %s" % (type(exc).__name__, exc)
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                return {"error": "skipped on all ranks: %s" % (why if not ok else "another rank could not set the training step up")}
+        elif not ok:
+            return {"error": why}
+        try:
+            return train_step_bench(args.train_batch, rank, world)
+        except Exception as exc:
+            if world > 1:          # the other ranks may be inside a collective: leave through the watchdog path, headline intact
+                if rank == 0 and result is not None:
+                    result["train_step"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                    _finalize_secondary(result)
+                    print(json.dumps(result), flush=True)
+                done.set()
+                os._exit(0 if rank == 0 else 3)
+            return {"error": "%s: %s" % (type(exc).__name__, exc)}
+    finally:
+        done.set()
+        if timer is not None:
+            timer.cancel()
+
+
+def _finalize_secondary(result):
+    """roofline.secondary: the scalars of the other BASELINE.json configs, inside the object the driver's record keeps."""
+    sec = {}
+    e = result.get("edit_step") or {}
+    if "p50_ms_one_call" in e:
+        sec["edit_p50_ms"] = e["p50_ms_one_call"]
+        sec["edit_frac"] = e["roofline"]["frac"]
+        sec["edit_frac_executed_bytes"] = e["roofline"].get("frac_executed")
+        sec["edit_p50_ms_two_calls"] = e.get("p50_ms")
+    f = result.get("full_ian") or {}
+    if "value" in f:
+        sec["full_ian_value"] = f["value"]
+        sec["full_ian_frac"] = (f.get("roofline") or {}).get("frac")
+    t = result.get("train_step") or {}
+    if "images_per_s" in t:
+        sec["train_images_per_s"] = t["images_per_s"]
+        sec["train_frac"] = t["roofline"]["frac"]
+        sec["train_update_gen_ms"], sec["train_update_discrim_ms"] = t["update_gen_ms"], t["update_discrim_ms"]
+        if "allreduce_exposed_ms" in t:
+            sec["train_allreduce_exposed_ms"] = sum(t["allreduce_exposed_ms"].values())
+    b = result.get("b1_recon") or {}
+    if "device_ms" in b:
+        sec["b1_recon_ms"] = b["device_ms"]
+        sec["b1_recon_frac"] = b["roofline"]["frac"]
+        sec["b1_recon_api_p50_ms"] = b.get("api_p50_ms")
+    if isinstance(result.get("roofline"), dict):
+        result["roofline"]["secondary"] = sec
 
 
 def _free_port():
@@ -241,6 +330,7 @@ def main(argv=None):
     ap.add_argument("--train", action="store_true", help="also time the train_IAN.py step (default: only on 1 GPU)")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-batch", type=int, default=128, help="per-GPU minibatch of the training step (config 5: 1024 over 8 GPUs)")
+    ap.add_argument("--train-timeout", type=int, default=420, help="N > 1: seconds after which the training leg is abandoned (the headline line is still printed)")
     ap.add_argument("--host-io", action="store_true", help="also time the API.py-style call: host numpy in, host numpy out (PCIe inclusive)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / aggregation plumbing only: no GPU work, value null "
                                                            "(tests/test_comm.py runs this with 2 gloo ranks on CPU)")
@@ -429,6 +519,10 @@ def main(argv=None):
                         "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                      "achieved": EDIT_STEP_BYTES / (float(np.percentile(lat5[20:], 50)) * 1e-3) / 1e9,
                                      "frac": EDIT_STEP_BYTES / (float(np.percentile(lat5[20:], 50)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "achieved_executed": EDIT_STEP_BYTES_EXECUTED / (float(np.percentile(lat5[20:], 50)) * 1e-3) / 1e9,
+                                     "frac_executed": EDIT_STEP_BYTES_EXECUTED / (float(np.percentile(lat5[20:], 50)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "executed_basis": "151 MB: with the decoder-forward cache an event runs ONE decoder forward (77 MB) + one "
+                                                       "backward-data sweep (74 MB); reported beside the 232 MB algorithmic basis",
                                      "traffic": None,
                                      "basis": "SURVEY 8(d): 232 MB algorithmic per brush event (2 decoder forwards + 1 backward-data at batch 1, "
                                               "weights uncached) over the p50 of one ian_brush_step call (host copies and the sync included); the "
@@ -445,6 +539,41 @@ def main(argv=None):
                     h.set_option("edit_graph", 1)
                 except Exception:
                     pass
+        # ---- batch-1 reconstruction latency (BASELINE.json configs[0]'s GPU twin; NPE.py:257-261 encode_images -> sample_at) ----
+        b1 = None
+        if arch == "IAN_simple":
+            try:
+                x1 = torch.from_numpy(O.make_images(1, seed=5)).cuda()
+                o1 = torch.empty_like(x1)
+                h.call("ian_reconstruct", x1, 1, o1, stream=stream)
+                if not os.environ.get("IAN_NO_AUTOTUNE"):
+                    h.autotune(1, 1, stream=stream)
+                for _ in range(20):
+                    h.call("ian_reconstruct", x1, 1, o1, stream=stream)
+                reps = 200
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(reps):
+                    h.call("ian_reconstruct", x1, 1, o1, stream=stream)
+                e1.record()
+                torch.cuda.synchronize()
+                dev_ms = e0.elapsed_time(e1) / reps
+                xh1 = O.make_images(1, seed=5)
+                lat_api = []
+                for _ in range(80):
+                    t = time.perf_counter()
+                    model.sample_at(model.encode_images(xh1))
+                    lat_api.append((time.perf_counter() - t) * 1e3)
+                ach = B1_RECON_BYTES / (dev_ms * 1e-3) / 1e9
+                b1 = {"device_ms": dev_ms, "api_p50_ms": float(np.percentile(lat_api[20:], 50)), "api_p95_ms": float(np.percentile(lat_api[20:], 95)),
+                      "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                   "basis": "SURVEY 8(d): 214 MB per batch-1 reconstruction (encoder 137 MB + decoder 77 MB, the weights), "
+                                            "floor 26.9 us at 8 TB/s; device_ms = HIP-event time of %d back-to-back ian_reconstruct calls on "
+                                            "device buffers / %d; api = encode_images + sample_at through the API.py surface (host numpy in/out, "
+                                            "two calls, two syncs)" % (reps, reps)}}
+            except Exception as exc:
+                b1 = {"error": "%s: %s" % (type(exc).__name__, exc)}
         host_io = None
         if args.host_io:
             xh = O.make_images(B, seed=100 + rank)
@@ -466,7 +595,7 @@ def main(argv=None):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s encode->z->decode reconstruction, batch %d per GPU, inputs resident in HBM"
                                    % (arch, B), "parallelism": "replicas x%d (no data-path collective)" % world},
-            "step_ms": main_r["step_ms"], "roofline": roofline, "cpu_baseline": cpu, "edit_step": edit,
+            "step_ms": main_r["step_ms"], "roofline": roofline, "cpu_baseline": cpu, "edit_step": edit, "b1_recon": b1,
         }
         if host_io:
             result["host_io"] = host_io
@@ -493,17 +622,15 @@ def main(argv=None):
     # ---- train_IAN.py step (BASELINE.json configs[4]): full IAN, data parallel, RCCL gradient all-reduce ----------
     train = None
     if not args.no_train:   # at N > 1 this is the data-parallel step: 128 images per GPU, SyncBN + MinibatchLayer all-gather ("exact")
-        try:
-            train = train_step_bench(args.train_batch, rank, world)
-        except Exception as exc:  # never let the secondary measurement take the headline number down
-            train = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        train = guarded_train_leg(args, rank, world, result, backend)
     if rank == 0 and result is not None:
         result["train_step"] = train
+        _finalize_secondary(result)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

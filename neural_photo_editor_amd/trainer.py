@@ -266,14 +266,76 @@ class _CAI:
                                          "version": 2, "strides": None}
 
 
+class _DLDevice(C.Structure):
+    _fields_ = [("device_type", C.c_int32), ("device_id", C.c_int32)]
+
+
+class _DLDataType(C.Structure):
+    _fields_ = [("code", C.c_uint8), ("bits", C.c_uint8), ("lanes", C.c_uint16)]
+
+
+class _DLTensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("device", _DLDevice), ("ndim", C.c_int32), ("dtype", _DLDataType), ("shape", C.POINTER(C.c_int64)),
+                ("strides", C.POINTER(C.c_int64)), ("byte_offset", C.c_uint64)]
+
+
+class _DLManagedTensor(C.Structure):
+    pass
+
+
+_DLDeleter = C.CFUNCTYPE(None, C.POINTER(_DLManagedTensor))
+_DLManagedTensor._fields_ = [("dl_tensor", _DLTensor), ("manager_ctx", C.c_void_p), ("deleter", _DLDeleter)]
+_dl_keep = {}
+
+
+@_DLDeleter
+def _dl_delete(mt):                                   # torch calls this when the aliasing tensor dies: drop our bookkeeping only
+    _dl_keep.pop(C.addressof(mt.contents), None)
+
+
+def _view_dlpack(torch, ptr, n, dtype):
+    """DLPack capsule over libian-owned device memory (kDLROCM), for torch builds whose __cuda_array_interface__ import is
+    unavailable; the memory is NOT freed by the deleter."""
+    shape = (C.c_int64 * 1)(n)
+    mt = _DLManagedTensor()
+    mt.dl_tensor.data = C.c_void_p(int(ptr))
+    mt.dl_tensor.device = _DLDevice(10, torch.cuda.current_device())          # kDLROCM
+    mt.dl_tensor.ndim = 1
+    mt.dl_tensor.dtype = _DLDataType(2, 64 if dtype == "f8" else 32, 1)       # kDLFloat
+    mt.dl_tensor.shape = C.cast(shape, C.POINTER(C.c_int64))
+    mt.dl_tensor.strides = None
+    mt.dl_tensor.byte_offset = 0
+    mt.manager_ctx = None
+    mt.deleter = _dl_delete
+    _dl_keep[C.addressof(mt)] = (mt, shape)
+    new = C.pythonapi.PyCapsule_New
+    new.restype, new.argtypes = C.py_object, [C.c_void_p, C.c_char_p, C.c_void_p]
+    return torch.from_dlpack(new(C.addressof(mt), b"dltensor", None))
+
+
+_view_mode = [None]
+
+
 def device_view(torch, ptr, shape, dtype="f4"):
     """torch tensor over ``ptr`` (device memory that outlives the view; libian owns it) -- no copy."""
     n = int(np.prod(shape)) if len(shape) else 1
     if n == 0 or not ptr:
         raise IanTrainError("device_view: null pointer or empty shape")
-    t = torch.as_tensor(_CAI(ptr, (n,), "<" + dtype), device="cuda")
-    if t.data_ptr() != int(ptr):
-        raise IanTrainError("device_view: torch copied the buffer instead of aliasing it")
+    t = None
+    if _view_mode[0] in (None, "cai"):
+        try:
+            t = torch.as_tensor(_CAI(ptr, (n,), "<" + dtype), device="cuda")
+            if t.data_ptr() != int(ptr):
+                t = None
+            else:
+                _view_mode[0] = "cai"
+        except Exception:
+            t = None
+    if t is None:
+        t = _view_dlpack(torch, ptr, n, dtype)
+        if t.data_ptr() != int(ptr):
+            raise IanTrainError("device_view: torch copied the buffer instead of aliasing it")
+        _view_mode[0] = "dlpack"
     return t.view(*shape)
 
 
