@@ -8,7 +8,7 @@ oracle/staged_twin.py evaluates the float64 graph AT THE HIP STEP'S OWN FORWARD 
 HIP activation, straight-through; kink branches taken from the HIP activations) and
 
   * each stage's LOCAL forward error (HIP output vs float64 stage applied to the HIP input) is held to 1e-4, the north-star
-    tolerance on float32 activations -- 151 stages of the five passes, batch-statistics batch-norm included;
+    tolerance on float32 activations -- the 91 named stages of the five passes, batch-statistics batch-norm included;
   * every gradient tensor of the three parameter groups is held to the float64 gradient at that point: what is left is the
     arithmetic of the backward kernels alone (tap-GEMM backward-data / backward-weight, batch-norm backward, MinibatchLayer,
     losses), which is what a backward bug would show up in.
@@ -132,13 +132,17 @@ def test_gradient_error_is_born_in_the_forward_conditioning_not_in_the_backward_
               "loss_vs_plain_float64": {k: abs(m[k] - Lp[k]) / max(1.0, abs(Lp[k])) for k in m if k in Lp},
               "loss_at_hip_point_vs_hip": {k: abs(m[k] - La[k]) / max(1.0, abs(La[k])) for k in m if k in La}}
     _diag("decomposition_%s_%s" % (case, which), report)
-    assert len(local) >= 140
-    # every stage of the training forward, taken alone: the north star's 1e-4 on float32 activations
-    assert local[0][0] < 1e-4, local[:6]
-    assert float(np.median([e for e, _ in local])) < 5e-6, local[:6]
+    assert len(local) == 91          # 3 encoder passes x 11 + 8 latent + 2 decoder passes x 25 named stages
+    # every stage of the training forward, taken alone: the north star asks 1e-4 on float32 activations; measured 2.7e-6 worst,
+    # 1.8e-7 median (round 4, MI355X) -> held to 1e-5 / 1e-6
+    assert local[0][0] < 1e-5, local[:6]
+    assert float(np.median([e for e, _ in local])) < 1e-6, local[:6]
     # the losses the step reports, against the float64 losses at the same activations (round-3 verdict: 1e-4, not 2e-4)
     for k, v in report["loss_at_hip_point_vs_hip"].items():
-        assert v < 1e-4, (k, v)
-    # the backward kernels alone: median at float32 round-off, every tensor well inside what a wrong tap / chunk / scale produces
-    assert float(np.median([e for e, _ in e_at])) < 2e-5, e_at[:6]
-    assert e_at[0][0] < 5e-4, e_at[:6]
+        assert v < 1e-5, (k, v)                                   # measured 1.3e-7
+    for k, v in report["loss_vs_plain_float64"].items():
+        assert v < 2e-5, (k, v)                                   # measured 1.4e-6: the forward losses are well conditioned
+    # the backward kernels alone: measured median 5e-7 .. 1.5e-6, worst tensor 3.1e-5 (a 2-element MDCL coefficient gradient,
+    # an inner product of ~10^5 terms) -> median at float32 round-off, every tensor within 2e-4
+    assert float(np.median([e for e, _ in e_at])) < 1e-5, e_at[:6]
+    assert e_at[0][0] < 2e-4, e_at[:6]

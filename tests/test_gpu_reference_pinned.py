@@ -160,17 +160,22 @@ def _grad_err(fx, tag, name, g):
 
 def test_training_functions_vs_reference_train_IAN():
     """update_gen / update_discrim as train_IAN.py:497-504 drives them, same X / Z / epsilon the reference run used.
+    Metrics: 2e-5 against the reference-executed float64 values (measured 1.4e-6).
     Gradients of a step taken from the initial parameters are compared per tensor (relative max-norm error) against the
-    float64 reference execution and JUDGED AGAINST THE FIXTURE'S 'noise32': how far the reference's own graph moves when
-    the stand-in evaluates it in float32 (batch statistics over 4 images, |.| kinks and the cancellation behind a
-    batch-norm make some tensors -- l_dec_fc2.W: 17 % -- ill-conditioned for ANY float32 implementation).  Bars: group
-    median <= 4 x the float32 evaluation's median + 1e-3; every tensor <= 12 x its own float32 noise + 2e-2.  The
-    additive floors are the MinibatchLayer's |a_b - a_b'| kinks (layers.py:507-511): decoder outputs of a random-weight
-    net are near-identical across the 4 samples, a last-bit difference in the forward flips sign(a_b - a_b') for some
-    of the 4x4x2500 pairs and moves every encoder gradient at the 1e-3 level -- the float32 evaluation of the stand-in
-    happened to flip none (its discrim0 median is 1.5e-5), the HIP forward flips a few (measured round 3: discrim0
-    median 7.5e-4, worst 1.6e-2; gen median 2.9e-3, worst 0.11 on B_a_coeff_3 whose own float32 noise is 1e-2).  The
-    sharp form of the encoder passes (well separated images, 2e-4) is test_gpu_train.test_encoder_passes_backward_sharp."""
+    float64 reference execution and JUDGED AGAINST THE FIXTURE'S 'noise32': how far the reference's own graph moves when the
+    stand-in evaluates it in float32.  What the comparison can and cannot show (round 4, measured):
+      * the composed gradient of this fixture is ill-conditioned for ANY float32 implementation (batch statistics over 4
+        near-identical decoder outputs, leaky-ReLU and |a_b - a_b'| kinks): noise32 itself reaches 17 % on l_dec_fc2.W, and
+        1-ulp perturbations of the layer outputs move single tensors by 1e-2..6e-2 with a 7x spread from seed to seed
+        (scripts/exp/fp32_noise_conditioning.py -> profiles/r04_fp32_conditioning.json);
+      * tests/test_gpu_decomposition.py evaluates the float64 graph AT THE HIP STEP'S OWN ACTIVATIONS on this very minibatch:
+        every stage's local forward error <= 2.7e-6, every gradient tensor within 3.1e-5 (median 1.2e-6) -- the residual seen
+        here is forward drift x conditioning, not backward arithmetic (profiles/r04_decomposition.json).  That test is the
+        sharp per-tensor guard; this one holds the DISTRIBUTION of the composed error to the float32 noise of the reference's
+        own graph: group median <= 2 x noise32's median, 90 % of the tensors <= 3 x their own noise32 + 1e-3, and no tensor
+        above 3 x the LARGEST noise32 of its update (one draw of a heavy-tailed quantity cannot bound another per tensor).
+    Round 3 (float32 one-pass batch variance) measured discrim0 median 7.5e-4 / gen worst 0.113; with the float64 batch
+    statistics of round 4: discrim0 median 9.3e-6 (noise32: 1.5e-5), gen median 1.4e-3 (1.1e-3), worst 1.6e-2 (noise32: 0.17)."""
     import torch
     from neural_photo_editor_amd.trainer import Trainer
     fx = np.load(os.path.join(GOLD, "ref_train_IAN.npz"))
@@ -187,7 +192,7 @@ def test_training_functions_vs_reference_train_IAN():
         names = fx[tag + "/metric_names"].tolist()
         for n, b in zip(names, fx[tag + "/metrics"]):
             if n != "discrim_acc":                                              # argmax count over 12 decisions
-                assert abs(m[n] - b) <= 2e-4 * max(1.0, abs(b)), (tag, n, m[n], b)
+                assert abs(m[n] - b) <= 2e-5 * max(1.0, abs(b)), (tag, n, m[n], b)
         tr.backward(which)
         tr._regularizers(which)
         errs, noise = {}, {}
@@ -197,21 +202,25 @@ def test_training_functions_vs_reference_train_IAN():
                 noise[name] = float(fx["%s/noise32/%s" % (tag, name)])
         assert sorted(errs) == sorted(fx[tag + "/params"].tolist())           # the reference's parameter groups
         ev, nv = np.array([errs[k] for k in errs]), np.array([noise[k] for k in errs])
+        over = sorted(((errs[k], noise[k], k) for k in errs if errs[k] > 3 * noise[k] + 1e-3), reverse=True)
         report[tag] = {"median": float(np.median(ev)), "max": float(ev.max()), "float32_eval_median": float(np.median(nv)),
-                       "float32_eval_max": float(nv.max()),
-                       "worst": sorted(((errs[k], noise[k], k) for k in errs), reverse=True)[:6]}
+                       "float32_eval_max": float(nv.max()), "tensors": len(errs), "above_3x_own_noise_plus_1e-3": over,
+                       "worst": sorted(((errs[k], noise[k], k) for k in errs), reverse=True)[:6],
+                       "all": sorted(((errs[k], noise[k], k) for k in errs), reverse=True)}
         _note("train_grad_rel_err", report)
-        assert np.median(ev) <= 4 * np.median(nv) + 1e-3, report[tag]
-        bad = [(k, errs[k], noise[k]) for k in errs if errs[k] > 12 * noise[k] + 2e-2]
-        assert not bad, bad
+        assert np.median(ev) <= 2 * np.median(nv), report[tag]["worst"]
+        assert len(over) <= 0.1 * len(errs), over
+        assert ev.max() <= 3 * nv.max(), report[tag]["worst"]
     # the alternation itself: update_gen(batch 0) then update_discrim(batch 1); the second step inherits the split of
     # Adam's sign-like first step (|step| ~ lr whatever |g|), so its metrics are held to 1e-2 and the parameters to
     # "much closer to the reference's end point than to the start"
     got = np.array(tr.update_gen(dev(X[:B]), dev(Z[:B]), dev(fx["gen/eps"])), np.float64)
-    assert np.allclose(got, fx["gen/metrics"], rtol=2e-4, atol=2e-4), (got, fx["gen/metrics"])
+    assert np.allclose(got, fx["gen/metrics"], rtol=2e-5, atol=2e-5), (got, fx["gen/metrics"])
     got = np.array(tr.update_discrim(dev(X[B:]), dev(Z[B:]), dev(fx["discrim/eps"])), np.float64)
     keep = [i for i, n in enumerate(fx["discrim/metric_names"].tolist()) if n != "discrim_acc"]
-    assert np.allclose(got[keep], fx["discrim/metrics"][keep], rtol=1e-2, atol=1e-3), (got, fx["discrim/metrics"])
+    _note("second_update_metric_rel_err", {n: float(abs(got[i] - fx["discrim/metrics"][i]) / max(1.0, abs(fx["discrim/metrics"][i])))
+                                           for i, n in enumerate(fx["discrim/metric_names"].tolist())})
+    assert np.allclose(got[keep], fx["discrim/metrics"][keep], rtol=2e-3, atol=2e-3), (got, fx["discrim/metrics"])
     assert tr.groups["Z"].t == 2 and tr.groups["dec"].t == 1 and tr.groups["enc"].t == 1     # ONE Adam instance for Z (:266-276)
     after = tr.params_numpy()
     moved, err = [], []

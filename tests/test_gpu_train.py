@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = os.path.join(ROOT, "neural_photo_editor_amd", "configs", "IAN.py")
 B = 4
-TOL_LOSS = 2e-4
+TOL_LOSS = 2e-5     # measured 1.4e-6 (tests/test_gpu_decomposition.py: loss_vs_plain_float64)
 TOL_GRAD = 3e-3
 
 
@@ -137,10 +137,13 @@ def test_gradients_match_autograd(setup, which):
         got = tr.grads_numpy(gname)
         errs = sorted(((rel(got[name], ref.numpy()), name) for name, ref in g[gname].items()), reverse=True)
         med, mx = float(np.median([e for e, _ in errs])), errs[0][0]
-        # 8x: the float32 twin's error is ONE draw of a heavy-tailed quantity (batch statistics over 4 images, |.| kinks,
-        # cancellation behind batch-norm); with the reference's MADE wiring (round 3) the HIP step sat at 5.5x of it
-        assert med < 8 * noise[gname][0] + 1e-4, (gname, med, noise[gname], errs[:5])
-        assert mx < 8 * noise[gname][1] + 1e-3, (gname, mx, noise[gname], errs[:5])
+        _diag("gradients_match_autograd_%s_%s" % (which, gname), {"median": med, "max": mx, "twin32_median": noise[gname][0],
+                                                                   "twin32_max": noise[gname][1], "worst": errs[:5]})
+        # the float32 twin's error is ONE draw of a heavy-tailed quantity (batch statistics over 4 images, |.| kinks); the sharp
+        # per-tensor form of this comparison is tests/test_gpu_decomposition.py.  Round 3: 8x / 8x with the float32 one-pass
+        # variance; round 4 (float64 statistics): median within 2x, worst tensor within 4x of the twin's draw
+        assert med < 2 * noise[gname][0] + 1e-5, (gname, med, noise[gname], errs[:5])
+        assert mx < 4 * noise[gname][1] + 1e-3, (gname, mx, noise[gname], errs[:5])
 
 
 def test_two_updates_of_each_kind_track_the_twin(setup):
@@ -215,6 +218,17 @@ def test_checkpoint_from_training_drives_the_inference_path(setup, tmp_path):
     assert rel(model.sample_at(z), ref) < 1e-4
     x = O.make_images(2, seed=9)
     assert rel(model.encode_images(x), O.Oracle("IAN", state).encode_images(x)) < 1e-4
+
+
+def _diag(name, obj):
+    import json
+    d = os.path.join(ROOT, "gpurun_out", "diag")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name + ".json"), "w") as fh:
+            json.dump(obj, fh, indent=1)
+    except OSError:
+        pass
 
 
 def torch_conv_features(tw, X):

@@ -194,7 +194,7 @@ def test_generator_update_at_the_benchmarked_batch():
     tr.forward(dev(X), dev(Z), dev(eps), xhat_override=dev(xh), xgen_override=dev(xg))
     m = tr.metrics()
     for k in ("pixel_loss", "kl_div", "feature_loss", "gen_recon_loss", "gen_sample_loss", "discrim_d_loss"):
-        assert abs(m[k] - float(L[k])) <= 2e-4 * max(1.0, abs(float(L[k]))), (k, m[k], float(L[k]))
+        assert abs(m[k] - float(L[k])) <= 2e-5 * max(1.0, abs(float(L[k]))), (k, m[k], float(L[k]))
     tr.backward("gen")
     tr._regularizers("gen")
     out = {}
@@ -203,8 +203,12 @@ def test_generator_update_at_the_benchmarked_batch():
         errs = sorted(((rel(got[name], r.numpy()), name) for name, r in ref[gname].items()), reverse=True)
         out[gname] = {"median": float(np.median([e for e, _ in errs])), "worst": errs[:5]}
     diag("composed128", out)
+    # median: 2 x the float32 twin's (round-3 verdict).  Worst tensor: the maximum of ~150 heavy-tailed draws; 1-ulp perturbations of
+    # the layer outputs move it by 7x from seed to seed (9e-3 .. 6.3e-2 at 16 images, profiles/r04_fp32_conditioning.json), so one
+    # float32 draw bounds another only within that spread: 8 x.  The sharp per-tensor guard is tests/test_gpu_decomposition.py
+    # (float64 gradient at the HIP step's own activations: every tensor within 3.1e-5).
     for gname in ("dec", "Z"):
-        assert out[gname]["median"] < 4 * TWIN32[gname][0] and out[gname]["worst"][0][0] < 10 * TWIN32[gname][1], (gname, out[gname])
+        assert out[gname]["median"] < 2 * TWIN32[gname][0] and out[gname]["worst"][0][0] < 8 * TWIN32[gname][1], (gname, out[gname])
 
 
 def test_encoder_passes_at_the_benchmarked_batch():
