@@ -133,8 +133,8 @@ hipError_t launch_deconv_out_nchw(const float* x, const float* w, const float* s
 hipError_t launch_dense_fwd_gemv(const float* x, const float* w, int K, int nout, const float* scale, const float* shift, int act,
                                  float* y, hipStream_t s);
 hipError_t launch_dense_bwd_gemv(const float* g, const float* wb, int rows, int K, const float* res, float* dz, hipStream_t s);
-hipError_t launch_deconv_out_px(const float* x, const float* w, const float* scale, const float* shift, float* y, int n, int H,
-                                int W, int Cin, int Cout, int act, hipStream_t s);
+hipError_t launch_deconv_out_px(const float* x, const float* w, const float* scale, const float* shift, float* y, float* mirror, int n,
+                                int H, int W, int Cin, int Cout, int act, hipStream_t s);
 
 // y = act(x*scale[c]+shift[c]) on NHWC tensors (pixel stride = stride)
 hipError_t launch_affine(const float* x, float* y, const float* scale, const float* shift, long long npix, int C,
@@ -256,7 +256,7 @@ struct PhotoBlendArgs {
   int radius;
 };
 hipError_t launch_photo_blend(const PhotoBlendArgs& a, hipStream_t s);
-hipError_t launch_latent_update(float* z, const float* g, const float* cg, int n, hipStream_t s);
+hipError_t launch_latent_update(float* z, const float* g, const float* cg, int n, float* z_mirror, float* g_mirror, hipStream_t s);
 hipError_t launch_to_uint8(const float* x, unsigned char* y, long long n, hipStream_t s);
 
 // identity-edge gradient hand-over: gd[p,c] (+)= gs[p,coff+c] * act'(y[p,c]) * scale[c]   (NHWC, strides ss / ds)

@@ -117,6 +117,7 @@ struct Options {
   int dec_out_px = 1;                // ... and, below that batch, 8 lanes per output pixel instead of 16 tile workgroups
   int dec_out_mfma = 1;              // image-producing deconv (IAN_simple dec_out) on the matrix cores for batches >= 4
   int edit_graph = 1;                // batch-1 host-pointer calls (the NPE edit loop) replay captured hipGraphs
+  int edit_zero_copy = 1;            // their kernels read the brush rectangle from / write z, dz, the image to the pinned block directly
   int head_fused = 1;                // RGB-Beta head as head6 + head_tail (kernels_head.hip) when the graph matches IAN.py:183-207
   int head_fused_min_n = 8;          // ... for batches of at least this many images (the latent brush's batch-1 backward
                                      // needs the per-layer activations of the unfused ops)
@@ -160,6 +161,7 @@ struct ian_handle {
   // its forward pass.  Any other use of the decoder slots invalidates it.
   long long run_serial = 0;  // incremented per executed segment (fused head bookkeeping)
   std::map<int, char> slot_stale;  // external-layout slots whose own buffer was bypassed by a device-pointer call (SlotAlias)
+  std::map<int, char> slot_aliased;  // ... and which of them are bound to a caller's buffer right now
   std::vector<float> dec_cache_z;
   std::vector<float> rgb_cache;  // host copy of the brush image last uploaded to d_rgb
   // NPE.paint photo blend (ian_photo_blend): device copies of RECON / ERROR with their host shadows, outputs
@@ -182,10 +184,18 @@ struct ian_handle {
     long long epoch = -1;
     int warm = 0;
     long long warm_epoch = -1;   // the eager pass counts only for the options / schedules / buffers it ran with
+    bool mirrors = false;        // its image kernel writes the pinned image as well (zero-copy): no device -> host copy needed
   };
   long long alloc_epoch = 0;
   hipStream_t edit_stream = nullptr;
   float* pin = nullptr;      // pinned host block: z [0,128) | dz [128,256) | image [256, 256+12288) | patch (4 ints) after that
+  // Round 4: the block is allocated mapped + coherent and the kernels of the interactive graphs read the brush rectangle from it
+  // and write the new latent, the gradient and the image into it directly (pin_dev = its device address; nullptr: not
+  // available, the graphs keep their copy nodes).  Every hipMemcpyAsync of a graph is a 4.6 us copy kernel plus a kernel
+  // boundary on this runtime: four of them per brush event.
+  float* pin_dev = nullptr;
+  float* out_mirror = nullptr;   // set around run_segment(DEC): the batch-1 image kernel also writes the image there
+  bool pin_img_valid = false;    // pin[PIN_IMG..] holds the image that is resident in the output slot
   int* d_patch = nullptr;
   EditGraph g_fwd, g_bwd[2], g_step[2][2];   // g_step[mode][image wanted]: backward + latent update + forward (ian_brush_step)
   bool graph_failed = false;

@@ -311,7 +311,10 @@ static hipError_t launch_deconv_out_cin(const float* x, const float* w, const fl
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void deconv_out_px_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            float* __restrict__ y, int n, int H, int W, int act) {
+                                                            float* __restrict__ y, float* __restrict__ mirror, int n, int H, int W,
+                                                            int act) {
+  // mirror (or nullptr): a second copy of the image, in practice the pinned host block of the interactive loop (zero-copy:
+  // the store goes over the fabric to host memory, which spares the graph a device -> host copy node)
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int part = gid & 7;
   const int opix = gid >> 3;
@@ -358,31 +361,34 @@ __global__ __launch_bounds__(256) void deconv_out_px_kernel(const float* __restr
     v += __shfl_xor(v, 4);
     if (part == 0) {
       const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
-      y[((size_t)(b * COUT + co) * OH + oy) * OW + ox] = m_act(v * sc + sh, act);
+      const float o = m_act(v * sc + sh, act);
+      const size_t yo = ((size_t)(b * COUT + co) * OH + oy) * OW + ox;
+      y[yo] = o;
+      if (mirror) mirror[yo] = o;
     }
   }
 }
 
 template <int CIN>
 static hipError_t launch_deconv_out_px_cin(const float* x, const float* w, const float* scale, const float* shift, float* y,
-                                           int n, int H, int W, int Cout, int act, hipStream_t s) {
+                                           float* mirror, int n, int H, int W, int Cout, int act, hipStream_t s) {
   const long long threads = (long long)n * 4 * H * W * 8;
   const dim3 grid((unsigned)((threads + 255) / 256));
   switch (Cout) {
-    case 1: hipLaunchKernelGGL((deconv_out_px_kernel<CIN, 1>), grid, dim3(256), 0, s, x, w, scale, shift, y, n, H, W, act); break;
-    case 2: hipLaunchKernelGGL((deconv_out_px_kernel<CIN, 2>), grid, dim3(256), 0, s, x, w, scale, shift, y, n, H, W, act); break;
-    case 3: hipLaunchKernelGGL((deconv_out_px_kernel<CIN, 3>), grid, dim3(256), 0, s, x, w, scale, shift, y, n, H, W, act); break;
-    case 4: hipLaunchKernelGGL((deconv_out_px_kernel<CIN, 4>), grid, dim3(256), 0, s, x, w, scale, shift, y, n, H, W, act); break;
+    case 1: hipLaunchKernelGGL((deconv_out_px_kernel<CIN, 1>), grid, dim3(256), 0, s, x, w, scale, shift, y, mirror, n, H, W, act); break;
+    case 2: hipLaunchKernelGGL((deconv_out_px_kernel<CIN, 2>), grid, dim3(256), 0, s, x, w, scale, shift, y, mirror, n, H, W, act); break;
+    case 3: hipLaunchKernelGGL((deconv_out_px_kernel<CIN, 3>), grid, dim3(256), 0, s, x, w, scale, shift, y, mirror, n, H, W, act); break;
+    case 4: hipLaunchKernelGGL((deconv_out_px_kernel<CIN, 4>), grid, dim3(256), 0, s, x, w, scale, shift, y, mirror, n, H, W, act); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
-hipError_t launch_deconv_out_px(const float* x, const float* w, const float* scale, const float* shift, float* y, int n, int H,
-                                int W, int Cin, int Cout, int act, hipStream_t s) {
+hipError_t launch_deconv_out_px(const float* x, const float* w, const float* scale, const float* shift, float* y, float* mirror, int n,
+                                int H, int W, int Cin, int Cout, int act, hipStream_t s) {
   if (Cout > 4 || Cout < 1) return hipErrorInvalidValue;
-  if (Cin == 128) return launch_deconv_out_px_cin<128>(x, w, scale, shift, y, n, H, W, Cout, act, s);
-  if (Cin == 64) return launch_deconv_out_px_cin<64>(x, w, scale, shift, y, n, H, W, Cout, act, s);
-  if (Cin == 256) return launch_deconv_out_px_cin<256>(x, w, scale, shift, y, n, H, W, Cout, act, s);
+  if (Cin == 128) return launch_deconv_out_px_cin<128>(x, w, scale, shift, y, mirror, n, H, W, Cout, act, s);
+  if (Cin == 64) return launch_deconv_out_px_cin<64>(x, w, scale, shift, y, mirror, n, H, W, Cout, act, s);
+  if (Cin == 256) return launch_deconv_out_px_cin<256>(x, w, scale, shift, y, mirror, n, H, W, Cout, act, s);
   return hipErrorInvalidValue;
 }
 

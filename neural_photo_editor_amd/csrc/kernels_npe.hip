@@ -117,18 +117,25 @@ __global__ __launch_bounds__(256) void to_uint8_kernel(const float* __restrict__
 // Z += coef * (dZ * gscale) in float32, every product rounded on its own (NPE.py:205-209: grad = temp*(1+(x2-x1));
 // Z -= weight*grad  ->  coef = -weight;  NPE.py:313-314 likewise with coef = sign*weight).  cg = {coef, gscale} in device memory
 // so that a captured graph can be replayed with other values.
+// z_mirror / g_mirror (or nullptr): the new latent and the gradient are also written there -- the pinned host block of the
+// interactive loop (zero-copy), which spares the captured graph two device -> host copy nodes; cg may live there as well.
 __global__ __launch_bounds__(128) void latent_update_kernel(float* __restrict__ z, const float* __restrict__ g,
-                                                            const float* __restrict__ cg, int n) {
+                                                            const float* __restrict__ cg, int n, float* __restrict__ z_mirror,
+                                                            float* __restrict__ g_mirror) {
   const int i = threadIdx.x;
   if (i < n) {
-    float t = g[i] * cg[1];
+    const float gi = g[i];
+    float t = gi * cg[1];
     t = cg[0] * t;
-    z[i] = z[i] + t;
+    const float zn = z[i] + t;
+    z[i] = zn;
+    if (z_mirror) z_mirror[i] = zn;
+    if (g_mirror) g_mirror[i] = gi;
   }
 }
-hipError_t launch_latent_update(float* z, const float* g, const float* cg, int n, hipStream_t s) {
+hipError_t launch_latent_update(float* z, const float* g, const float* cg, int n, float* z_mirror, float* g_mirror, hipStream_t s) {
   if (n > 128) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(latent_update_kernel, dim3(1), dim3(128), 0, s, z, g, cg, n);
+  hipLaunchKernelGGL(latent_update_kernel, dim3(1), dim3(128), 0, s, z, g, cg, n, z_mirror, g_mirror);
   return hipGetLastError();
 }
 hipError_t launch_to_uint8(const float* x, unsigned char* y, long long n, hipStream_t s) {

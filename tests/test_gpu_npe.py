@@ -124,6 +124,53 @@ def test_brush_step_equals_the_composed_calls(model, graph):
         model.handle.set_option("edit_graph", 1)
 
 
+def test_zero_copy_graphs_equal_the_copy_node_graphs(model):
+    """Round 4: the kernels of the interactive graphs read the brush rectangle from the pinned host block and write the new
+    latent, the gradient and the image into it directly (no hipMemcpy nodes).  Same kernels, same arithmetic: the events must be
+    bit-identical to the graphs with copy nodes (edit_zero_copy = 0), also when the decoder cache short-cuts a call and when
+    sample_at / imgradRGB interleave with brush_step."""
+    from neural_photo_editor_amd import npe_ops as N
+    IM, Z, RECON, ERROR = session(model, 17)
+    rgb = np.float32(N.to_tanh(np.float32(_rgb_image())))[None]
+    runs = {}
+    try:
+        for zc in (0, 1):
+            model.handle.set_option("edit_zero_copy", zc)
+            z = np.float32(Z).copy()
+            rec = []
+            for i in range(10):
+                box = (18 + i, 20, 23 + i, 25 + (i % 2))
+                if i % 4 == 3:                                   # a two-call event in between (its own graphs)
+                    g = model.imgradRGB(box[0], box[1], box[2], box[3], rgb, z)
+                    z = np.float32(z - np.float32(0.05) * (g * np.float32(1 + (box[2] - box[0]))))
+                    rec.append((z.copy(), model.sample_at(z), model.sample_at(z)))       # second call: decoder-cache hit
+                else:
+                    z, x = model.brush_step(box[0], box[1], box[2], box[3], z, RGB=rgb, weight=0.05)
+                    rec.append((z.copy(), x, model.sample_at(z)))                           # cache hit right after the event
+            runs[zc] = rec
+    finally:
+        model.handle.set_option("edit_zero_copy", 1)
+    for (za, xa, ya), (zb, xb, yb) in zip(runs[0], runs[1]):
+        assert np.array_equal(za, zb) and np.array_equal(xa, xb) and np.array_equal(ya, yb)
+        assert np.array_equal(xb, yb)                                                      # the cached image is the event's image
+    assert np.abs(runs[1][-1][0] - np.float32(Z)).max() > 1e-4
+
+
+def test_activation_readable_after_device_pointer_call_then_host_call(model):
+    """a device-pointer ian_reconstruct marks the output slot's own buffer stale; any later call that refills that
+    buffer (sample_at, the decoder cache, the graphs, brush_step) must make it readable again."""
+    import torch
+    from neural_photo_editor_amd import synthetic as O
+    x = torch.from_numpy(O.make_images(1, seed=4)).cuda()
+    out = torch.empty_like(x)
+    model.handle.call("ian_reconstruct", x, 1, out)
+    torch.cuda.synchronize()
+    z = O.make_latents(1, seed=6)
+    img = model.sample_at(z)
+    got = model.handle.read_slot(model.lowered.out_slot, 1)          # used to fail: "bound to the caller's device buffer ..."
+    assert np.array_equal(got, img)
+
+
 def test_paint_event_photo_mode(model):
     """NPE.paint in photo mode as one submission: (Z_new, IM) == brush_step + photo_blend_host on the decoded image."""
     from neural_photo_editor_amd import npe_ops as N
