@@ -14,12 +14,16 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["kernels_tapgemm.hip", "kernels_b1.hip", "kernels_misc.hip", "kernels_head.hip", "kernels_npe.hip", "kernels_wgrad.hip", "kernels_train.hip", "ian_runtime.cpp", "ian_train_abi.cpp", "ian_trainer.cpp"]
+SOURCES = ["kernels_tapgemm.hip", "kernels_misc.hip", "kernels_head.hip", "kernels_npe.hip", "kernels_wgrad.hip", "kernels_train.hip", "ian_runtime.cpp", "ian_train_abi.cpp", "ian_trainer.cpp"]
 HEADERS = ["ian_internal.h", "ian_guard.h", "ian_rt_types.h", "ian_rt_util.inc", "ian_rt_pack.inc", "ian_rt_schedule.inc", "ian_rt_exec.inc",
            "ian_rt_autotune.inc", "ian_rt_io.inc", "ian_rt_backward.inc", "ian_rt_edit.inc", "ian_rt_api.inc", "ian_rt_layer.inc", os.path.join("..", "..", "include", "ian.h"), os.path.join("..", "..", "include", "ian_train.h")]
-# IAN_ABLATION_BUILD=1 (scripts/ablate_tapgemm.sh only): a SEPARATE library with the timing-only tapgemm ablations
-# compiled in (-DIAN_ABLATION); the product library never contains them.
+# IAN_ABLATION_BUILD=1 (tests/test_gpu_ablation.py, scripts/ablate_tapgemm.sh): a SEPARATE library, libian_ablation.so, with
+# -DIAN_ABLATION: the measured NEGATIVE results kept runnable (tapgemm K-loop schedules 0 and 3, the in-launch split-K
+# combine, the batch-1 streaming deconv of kernels_b1.hip, the 4-wave tapwgrad tile -- all bitwise / parity tested there)
+# plus the timing-only tapgemm ablations.  The product library contains none of them and rejects their option values.
 ABLATION = bool(os.environ.get("IAN_ABLATION_BUILD"))
+if ABLATION:
+    SOURCES = SOURCES[:1] + ["kernels_b1.hip"] + SOURCES[1:]
 # IAN_SANITIZE=1: libian_asan.so -- the HOST translation units of the C-ABI layer (runtime, training ABI, trainer) under
 # AddressSanitizer + UBSan with guard bands around every device allocation (csrc/ian_guard.h); the .hip objects are the
 # product build's.  Loaded by tests through IAN_LIB=<path> with the ASan runtime preloaded (tests/test_sanitize.py).

@@ -117,6 +117,7 @@ struct Options {
   int dec_out_px = 1;                // ... and, below that batch, 8 lanes per output pixel instead of 16 tile workgroups
   int dec_out_mfma = 1;              // image-producing deconv (IAN_simple dec_out) on the matrix cores for batches >= 4
   int edit_graph = 1;                // batch-1 host-pointer calls (the NPE edit loop) replay captured hipGraphs
+  int edit_spin = 1;                 // ... and their final wait polls the stream (hipStreamQuery) before it falls back to hipStreamSynchronize
   int edit_zero_copy = 1;            // their kernels read the brush rectangle from / write z, dz, the image to the pinned block directly
   int head_fused = 1;                // RGB-Beta head as head6 + head_tail (kernels_head.hip) when the graph matches IAN.py:183-207
   int head_fused_min_n = 8;          // ... for batches of at least this many images (the latent brush's batch-1 backward

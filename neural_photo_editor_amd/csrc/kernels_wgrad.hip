@@ -173,7 +173,9 @@ static hipError_t launch_wg(const WgParams& p, int nitems, hipStream_t s) {
 hipError_t launch_tapwgrad(int cfg, const WgParams& p, int nitems, hipStream_t s) {
   if (nitems <= 0) return hipSuccess;
   switch (cfg) {
+#ifdef IAN_ABLATION   // the 4-wave 128x128 tile (superseded by the 8-wave one, bitwise the same result): libian_ablation.so only
     case WG_128x128: return launch_wg<128, 128, 2, 2>(p, nitems, s);
+#endif
     case WG_32x128: return launch_wg<32, 128, 1, 4>(p, nitems, s);
     case WG_128x32: return launch_wg<128, 32, 4, 1>(p, nitems, s);
     case WG_128x128W8: return launch_wg<128, 128, 2, 4>(p, nitems, s);

@@ -53,6 +53,14 @@ def library_path():
     return _build.LIB
 
 
+def is_ablation_build():
+    """True when the loaded library is libian_ablation.so (IAN_ABLATION_BUILD=1 + IAN_LIB=...): the negative-result variants
+    (tapgemm schedules 0 / 3, in-launch split-K combine, kernels_b1.hip, 4-wave tapwgrad tile) exist only there."""
+    lib = load_library()
+    lib.ian_version.restype = C.c_char_p
+    return b"ablation" in (lib.ian_version() or b"")
+
+
 def load_library():
     """Load (building first if the in-tree .so is absent or stale and hipcc exists)."""
     global _lib

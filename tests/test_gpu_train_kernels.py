@@ -562,7 +562,11 @@ def test_thin_mdcl_lds_staged_equals_direct(env, cin, monkeypatch):
 @pytest.mark.parametrize("kind", ["conv", "deconv"])
 def test_backward_weight_eight_wave_tile_is_bitwise_the_four_wave_tile(env, kind, monkeypatch):
     """tapwgrad with 8-wave 128x128 workgroups (default) and with the 4-wave ones (wg_w8=0): every output element
-    accumulates the same products in the same order -> identical weight gradients."""
+    accumulates the same products in the same order -> identical weight gradients.  The 4-wave tile is compiled into
+    libian_ablation.so only (tests/test_gpu_ablation.py runs this test against it)."""
+    from neural_photo_editor_amd.lib import is_ablation_build
+    if not is_ablation_build():
+        pytest.skip("the superseded 4-wave tapwgrad tile exists in libian_ablation.so only")
     lib, T, k = env
     n, cin, cout, h = 8, 128, 256, 16
     rs = np.random.RandomState(123)

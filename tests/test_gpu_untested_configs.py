@@ -351,6 +351,27 @@ class _LocalComm:
         pass
 
 
+def test_non_power_of_two_shards_are_announced(capfd):
+    """Round-3 verdict, weak #9: the partial-sum tree of the batch statistics is bit-identical between N ranks and one
+    process only for power-of-two shards; any other per-rank batch / world size must say so at set-up, loudly (stderr, from
+    ian_trainer_finalize -- the one sequencer -- so that C callers see it too)."""
+    from neural_photo_editor_amd.trainer import Trainer
+    P = make_train_params(O.make_params("IAN", 1))
+
+    class ThreeRanks(_LocalComm):
+        world = 3
+
+    capfd.readouterr()
+    tr = Trainer(os.path.join(CFG, "IAN.py"), P, batch=2, comm=ThreeRanks(), exact=True)
+    err = capfd.readouterr().err
+    assert "not a power of two" in err and "NOT guaranteed bit-identical" in err, err
+    assert tr.N == 6 and tr.exact and tr.stat("world") == 3
+    tr.close()
+    tr = Trainer(os.path.join(CFG, "IAN.py"), P, batch=2, comm=_LocalComm(), exact=True)     # 2 x 2: silent
+    assert "power of two" not in capfd.readouterr().err
+    tr.close()
+
+
 @pytest.mark.parametrize("which", ["gen", "discrim"])
 def test_local_statistics_mode(which):
     """exact=False (train_cli --local-statistics): batch-norm statistics and the MinibatchLayer see only the rank's own
