@@ -541,7 +541,7 @@ def main(argv=None):
                     pass
         # ---- batch-1 reconstruction latency (BASELINE.json configs[0]'s GPU twin; NPE.py:257-261 encode_images -> sample_at) ----
         b1 = None
-        if arch == "IAN_simple":
+        if arch == "IAN_simple" and not args.no_edit:   # --no-edit (scripts/profile_round.sh): batch-64 launches only in the trace
             try:
                 x1 = torch.from_numpy(O.make_images(1, seed=5)).cuda()
                 o1 = torch.empty_like(x1)

@@ -45,9 +45,11 @@ static inline int grid_for(long long total, int cap = 8192) {
 //   mode 2: g = dA*act'(a): s1 = sum g                        (bias gradient)
 // grid = (row chunks, column groups); block shape below.
 //
-// NUMERICS (round 4).  Every float32 element is widened to float64 BEFORE it is squared / multiplied / added, and all partial
-// sums, the tree and the mean / variance arithmetic stay in float64; only mean, inv_std, scale, shift (and the gradients
-// dbeta, dgamma) are rounded to float32, once.  x*x is exact in float64, the sums carry a relative error of ~1e-16 * n, so
+// NUMERICS (round 4).  Forward statistics (mode 0): every float32 element is widened to float64 BEFORE it is squared / added, and
+// all partial sums, the tree and the mean / variance arithmetic stay in float64; only mean, inv_std, scale, shift are rounded
+// to float32, once.  Gradient sums (modes 1, 2): the per-element values g and g*xhat are float32 (they are float32 data), four
+// rows are added in float32, everything longer -- chunk, tree, rank combine -- accumulates in float64; dbeta / dgamma are rounded
+// to float32 once.  x*x is exact in float64, the sums carry a relative error of ~1e-16 * n, so
 // var = E[x^2] - E[x]^2 is accurate to ~1e-13 * mean^2 -- BETTER conditioned than the float32 two-pass input.var(axes)
 // of Lasagne's BatchNormLayer (oracle/refexec/minilasagne.py:607) that rounds 1e-7 per operation.  Rounds 1-3 formed the same
 // one-pass expression in float32, whose cancellation error scales with mean^2 / var.  The kernels are HBM-bound; the
@@ -82,11 +84,10 @@ __global__ __launch_bounds__(256) void colstats_kernel(ColStatsArgs a) {
   const d4 dzero = {0.0, 0.0, 0.0, 0.0};
   d4 s1[4] = {dzero, dzero, dzero, dzero}, s2[4] = {dzero, dzero, dzero, dzero};
   if (c < a.C && r0 < r1) {
-    d4 mean = dzero, istd = dzero;
+    float4 fmean = zero, fistd = zero;
     if (MODE == 1) {
-      const float4 m = *reinterpret_cast<const float4*>(a.mean + c), is = *reinterpret_cast<const float4*>(a.inv_std + c);
-      mean = {m.x, m.y, m.z, m.w};
-      istd = {is.x, is.y, is.z, is.w};
+      fmean = *reinterpret_cast<const float4*>(a.mean + c);
+      fistd = *reinterpret_cast<const float4*>(a.inv_std + c);
     }
     for (long long r = r0 + rl; r < r1; r += 4 * RL) {
       float4 x[4], av[4], y[4];
@@ -100,20 +101,39 @@ __global__ __launch_bounds__(256) void colstats_kernel(ColStatsArgs a) {
         if (MODE != 0 && a.act) av[j] = *reinterpret_cast<const float4*>(a.a + off);
         if (MODE == 1) y[j] = *reinterpret_cast<const float4*>(a.y + off);
       }
+      if (MODE == 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float4 v = x[j];
-        if (MODE != 0 && a.act) {   // g = dA * act'(a): one float32 product, the value the apply kernel forms as well
-          v.x *= t_dact(av[j].x, a.act); v.y *= t_dact(av[j].y, a.act); v.z *= t_dact(av[j].z, a.act); v.w *= t_dact(av[j].w, a.act);
+        for (int j = 0; j < 4; ++j) {
+          const float4 v = ok[j] ? x[j] : zero;
+          const d4 w = {v.x, v.y, v.z, v.w};
+          d4_add(s1[j], w);
+          s2[j].x += w.x * w.x; s2[j].y += w.y * w.y; s2[j].z += w.z * w.z; s2[j].w += w.w * w.w;   // exact products
         }
-        if (!ok[j]) v = zero;
-        const d4 w = {v.x, v.y, v.z, v.w};
-        d4_add(s1[j], w);
-        if (MODE == 0) {
-          s2[j].x += w.x * w.x; s2[j].y += w.y * w.y; s2[j].z += w.z * w.z; s2[j].w += w.w * w.w;
-        } else if (MODE == 1) {
-          s2[j].x += w.x * (((double)y[j].x - mean.x) * istd.x); s2[j].y += w.y * (((double)y[j].y - mean.y) * istd.y);
-          s2[j].z += w.z * (((double)y[j].z - mean.z) * istd.z); s2[j].w += w.w * (((double)y[j].w - mean.w) * istd.w);
+      } else {
+        // gradient sums: g = dA * act'(a) and g * xhat are formed in float32 (the values bn_bwd_apply forms as well) and the four
+        // rows of this pass are added in float32, (0+1)+(2+3); the LONG accumulation -- over the chunk, the tree -- is float64.
+        // (All-float64 products made this pass compute-bound: 112 -> 155 us per call at 128 images.)
+        float4 g[4], t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float4 v = x[j];
+          if (a.act) {
+            v.x *= t_dact(av[j].x, a.act); v.y *= t_dact(av[j].y, a.act); v.z *= t_dact(av[j].z, a.act); v.w *= t_dact(av[j].w, a.act);
+          }
+          if (!ok[j]) v = zero;
+          g[j] = v;
+          if (MODE == 1) {
+            t[j].x = v.x * ((y[j].x - fmean.x) * fistd.x); t[j].y = v.y * ((y[j].y - fmean.y) * fistd.y);
+            t[j].z = v.z * ((y[j].z - fmean.z) * fistd.z); t[j].w = v.w * ((y[j].w - fmean.w) * fistd.w);
+          }
+        }
+        const d4 gs = {(double)((g[0].x + g[1].x) + (g[2].x + g[3].x)), (double)((g[0].y + g[1].y) + (g[2].y + g[3].y)),
+                       (double)((g[0].z + g[1].z) + (g[2].z + g[3].z)), (double)((g[0].w + g[1].w) + (g[2].w + g[3].w))};
+        d4_add(s1[0], gs);
+        if (MODE == 1) {
+          const d4 ts = {(double)((t[0].x + t[1].x) + (t[2].x + t[3].x)), (double)((t[0].y + t[1].y) + (t[2].y + t[3].y)),
+                         (double)((t[0].z + t[1].z) + (t[2].z + t[3].z)), (double)((t[0].w + t[1].w) + (t[2].w + t[3].w))};
+          d4_add(s2[0], ts);
         }
       }
     }
