@@ -28,7 +28,9 @@ struct TgItem {  // one workgroup's job (host-built table, 32 B)
   int pad1;
 };
 struct TgTile {  // reduce pass: one output tile
-  int cls, m0, n0, slab0, nsplit, pad0, pad1, pad2;
+  int cls, m0, n0, slab0, nsplit;
+  int py, px;  // the class's output parity offset, copied here so that the reduce pass needs ONE table load, not two dependent ones
+  int pad2;
 };
 
 enum { TG_EPI_FWD = 0, TG_EPI_BWD = 1 };

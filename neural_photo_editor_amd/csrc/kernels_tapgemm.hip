@@ -547,8 +547,7 @@ __device__ __forceinline__ void tg_reduce_body(const TgReduceParams& p) {
   constexpr int RPI = 256 / (CG * KP);  // rows per block
   constexpr int RG = BM / RPI;          // row groups per tile
   __shared__ float4 part[KP > 1 ? 256 : 1];
-  const TgTile t = p.tiles[blockIdx.x / RG];
-  const TgClass cl = p.classes[t.cls];
+  const TgTile t = p.tiles[blockIdx.x / RG];   // carries the class's (py, px): no dependent load of the class table
   const int kp = threadIdx.x / (CG * RPI);
   const int rem_t = threadIdx.x % (CG * RPI);
   const int cg = rem_t % CG;
@@ -594,7 +593,7 @@ __device__ __forceinline__ void tg_reduce_body(const TgReduceParams& p) {
   if (!live) return;
   const int n = m >> p.qhw_shift;
   const int rem = m & qhw_mask;
-  const int oy = (rem >> p.qw_shift) * p.so + cl.py, ox = (rem & qw_mask) * p.so + cl.px;
+  const int oy = (rem >> p.qw_shift) * p.so + t.py, ox = (rem & qw_mask) * p.so + t.px;
   const size_t pix = ((size_t)n * p.OH + oy) * p.OW + ox;
   const int c = t.n0 + cg * 4;
   const size_t yoff = pix * p.y_stride + c;

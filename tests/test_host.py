@@ -224,7 +224,9 @@ def test_headers_are_plain_c_and_ctypes_mirrors_their_structs(tmp_path):
     import subprocess
     if not shutil.which("gcc"):
         pytest.skip("no gcc")
-    mirrors = {"ian_op_desc": L.OpDesc, "ian_slot_desc": L.SlotDesc, "ian_model_desc": L.ModelDesc, "ian_photo_args": L.PhotoArgs}
+    from neural_photo_editor_amd import trainer as T
+    mirrors = {"ian_op_desc": L.OpDesc, "ian_slot_desc": L.SlotDesc, "ian_model_desc": L.ModelDesc, "ian_photo_args": L.PhotoArgs,
+               "ian_train_config": T.TrainConfig, "ian_comm_ops": T.CommOps}     # the training entry's config and collective table
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ian.h"', '#include "ian_train.h"', 'int main(void) {']
     for cname, cls in mirrors.items():
         lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
@@ -267,11 +269,36 @@ def test_missing_parameter_is_an_error_in_the_c_layer():
     h.close()
 
 
+def test_collective_table_callbacks_report_errors_as_return_codes():
+    """trainer.build_ops (the ian_comm_ops filler): Python exceptions never cross the C boundary -- the C side sees a non-zero
+    return code (and fails the step with -30), the exception is kept for the error message; arguments arrive as plain ints."""
+    from neural_photo_editor_amd import trainer as T
+    seen, errors = [], []
+
+    def allreduce(buf, count, stream):
+        seen.append(("ar", buf, count, stream))
+
+    def wait_all(stream):
+        raise RuntimeError("collective backend went away")
+
+    def allgather(src, dst, count, stream):
+        seen.append(("ag", src, dst, count, stream))
+
+    ops = T.build_ops(4, 2, allreduce, wait_all, allgather, errors)
+    assert (ops.world, ops.rank) == (4, 2)
+    assert ops.allreduce_sum(None, 0x1000, 77, 0x2000) == 0 and seen[-1] == ("ar", 0x1000, 77, 0x2000)
+    assert ops.allgather(None, 0x10, 0x20, 5, None) == 0 and seen[-1] == ("ag", 0x10, 0x20, 5, None)
+    assert ops.wait_all(None, 0) == 1 and len(errors) == 1 and "went away" in str(errors[0])
+
+
 def test_training_abi_exports_every_header_symbol():
     """include/ian_train.h: every declared entry point resolves in libian.so and gets its prototype from the header."""
     lib = L.load_train_library()
     names = L.train_exports()
     assert len(names) >= 39 and "ian_layer_backward_weight" in names and "ian_k_adam" in names
+    for n in ("ian_train_step", "ian_trainer_set_comm", "ian_trainer_forward", "ian_trainer_backward", "ian_trainer_finish_allreduce",
+              "ian_trainer_buffer", "ian_k_axpy_f64"):
+        assert n in names, n
     for n in names:
         assert getattr(lib, n).argtypes is not None
 
