@@ -97,7 +97,8 @@ struct Options {
   int tg_no_split_items = 384;  // do not split when tiles alone give at least this many workgroups
   int tg_split = 1;
   int tg_xcd_group = 8;       // supergroup edge (tiles) dealt to one XCD
-  int tg_xcd_spatial = 1;            // equal-weight runs of tile groups are dealt to the XCDs in contiguous (spatial) pieces, not round-robin
+  int tg_xcd_spatial = 0;            // experiment (round 4, OFF): equal-weight runs of tile groups dealt to the XCDs in contiguous pieces instead of
+                                     // round-robin.  Measured: same step time, HBM fetch per tapgemm launch 85 -> 122 MB at batch 64
   int tg_prefer_nosplit = 1;  // try smaller tiles before resorting to split-K
   int tg_nosplit_min_out = 1 << 30;  // outputs (M*Cout) above which 64x64 is forced even if it under-fills
   int mdc_head = 2;                  // few-filter MDCL layers: 0 = tapgemm, 1 = VALU head kernel, 2 = + sibling layers fused
