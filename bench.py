@@ -134,6 +134,27 @@ def pmc_traffic(arch, B):
         return None, None
 
 
+def train_pmc_traffic(batch):
+    """HBM bytes per update of the training step from the committed rocprofv3 PMC passes (profiles/r*_train_ian_b128.json, written by
+    scripts/profile_train.sh + scripts/summarize_train_profile.py); None when absent, taken at another batch, or taken on other kernel
+    sources than the ones running now (csrc digest)."""
+    import glob
+    if batch != 128:
+        return None, "PMC profile exists for 128 images per GPU only"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_train_ian_b128.json")))
+    if not files:
+        return None, None
+    try:
+        from neural_photo_editor_amd import build as _b
+        js = json.load(open(files[-1]))
+        src = os.path.relpath(files[-1], ROOT)
+        if js.get("csrc_digest") != _b._digest():
+            return None, "%s is stale (csrc digest %s != current %s)" % (src, str(js.get("csrc_digest"))[:12], _b._digest()[:12])
+        return float(js["hbm_bytes_per_update"]), "bytes per update, mean of update_gen and update_discrim (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % src
+    except Exception:
+        return None, None
+
+
 def train_step_bench(batch, rank, world, iters=3):
     """ms per update_gen / update_discrim (train_IAN.py:309-329) of the full IAN at `batch` images per GPU.  The SAME entry
     at every world size: ian_train_step (csrc/ian_trainer.cpp); at N > 1 its collectives arrive through the ian_comm_ops
@@ -170,7 +191,7 @@ def train_step_bench(batch, rank, world, iters=3):
     flops = batch * (TRAIN_FLOP_PER_IMAGE["gen"] + TRAIN_FLOP_PER_IMAGE["discrim"])
     ach = flops / (pair * 1e-3) / 1e12
     out["roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS, "achieved": ach, "frac": ach / FP32_MFMA_PEAK_TFLOPS,
-                       "traffic": None, "per_gpu": True,
+                       "traffic": train_pmc_traffic(batch)[0], "traffic_unit": train_pmc_traffic(batch)[1], "per_gpu": True,
                        "flop_per_image": {"update_gen": TRAIN_FLOP_PER_IMAGE["gen"], "update_discrim": TRAIN_FLOP_PER_IMAGE["discrim"]},
                        "frac_update_gen": batch * TRAIN_FLOP_PER_IMAGE["gen"] / (out["update_gen_ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                        "frac_update_discrim": batch * TRAIN_FLOP_PER_IMAGE["discrim"] / (out["update_discrim_ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
