@@ -351,7 +351,7 @@ def main(argv=None):
     ap.add_argument("--train", action="store_true", help="also time the train_IAN.py step (default: only on 1 GPU)")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-batch", type=int, default=128, help="per-GPU minibatch of the training step (config 5: 1024 over 8 GPUs)")
-    ap.add_argument("--train-timeout", type=int, default=420, help="N > 1: seconds after which the training leg is abandoned (the headline line is still printed)")
+    ap.add_argument("--train-timeout", type=int, default=300, help="N > 1: seconds after which the training leg is abandoned (the headline line is still printed)")
     ap.add_argument("--host-io", action="store_true", help="also time the API.py-style call: host numpy in, host numpy out (PCIe inclusive)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / aggregation plumbing only: no GPU work, value null "
                                                            "(tests/test_comm.py runs this with 2 gloo ranks on CPU)")
