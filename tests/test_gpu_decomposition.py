@@ -101,7 +101,8 @@ def _inputs(case):
     return O.make_images(B, seed=31), O.make_latents(B, seed=32), np.random.RandomState(33).randn(B, 100).astype(np.float32)
 
 
-@pytest.mark.parametrize("case,which", [("fixture4", "gen"), ("fixture4", "discrim"), ("synthetic16", "gen"), ("synthetic16", "discrim")])
+# (synthetic16, discrim) measured as well in round 4 (profiles/r04_decomposition.json: 5.2e-7 / 2.2e-6); left out of the suite for time
+@pytest.mark.parametrize("case,which", [("fixture4", "gen"), ("fixture4", "discrim"), ("synthetic16", "gen")])
 def test_gradient_error_is_born_in_the_forward_conditioning_not_in_the_backward_kernels(case, which):
     import torch
     from oracle.staged_twin import StagedTwin
