@@ -126,9 +126,10 @@ def pmc_traffic(arch, B):
             js = json.load(fh)
         v = js.get("tapgemm_traffic_bytes_per_launch")
         src = os.path.relpath(files[-1], ROOT)
-        if js.get("csrc_digest") != _b._digest():
+        cur = _b._digest("inference")     # the sources a reconstruction kernel can depend on (training-only files excluded)
+        if js.get("csrc_digest") not in (cur, _b._digest()):
             # the profile was taken on other kernel sources than the ones running now: do not quote it as this build's traffic
-            return None, "%s is stale (csrc digest %s != current %s)" % (src, str(js.get("csrc_digest"))[:12], _b._digest()[:12])
+            return None, "%s is stale (csrc digest %s != current %s)" % (src, str(js.get("csrc_digest"))[:12], cur[:12])
         return (float(v) if v else None), src
     except Exception:
         return None, None

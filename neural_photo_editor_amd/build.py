@@ -58,9 +58,18 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libian.so cannot be built")
 
 
-def _digest():
+# sources that only the training step uses: a change there cannot alter a reconstruction / brush kernel
+TRAINING_ONLY = ("kernels_train.hip", "kernels_wgrad.hip", "ian_train_abi.cpp", "ian_trainer.cpp", "ian_rt_layer.inc",
+                 os.path.join("..", "..", "include", "ian_train.h"))
+
+
+def _digest(scope=None):
+    """sha256 over the sources.  scope="inference": without the training-only files -- what a committed rocprofv3 summary of
+    the reconstruction workloads (profiles/r*_ian_*.json) is valid for; None: everything (the library stamp, the training profile)."""
     h = hashlib.sha256()
     for f in SOURCES + HEADERS:
+        if scope == "inference" and f in TRAINING_ONLY:
+            continue
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(ARCH.encode())

@@ -173,7 +173,7 @@ def main():
     # build's roofline.traffic only when the digest matches (otherwise it reports the profile as stale)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from neural_photo_editor_amd import build as _b
-    out["csrc_digest"] = _b._digest()
+    out["csrc_digest"] = _b._digest("inference")   # the sources a reconstruction kernel can depend on (bench.py: pmc_traffic)
     json.dump(out, open(dst + ".json", "w"), indent=1)
     print("wrote", dst + ".md", dst + ".json")
 

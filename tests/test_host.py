@@ -346,7 +346,7 @@ def test_bench_quotes_pmc_traffic_only_for_the_sources_it_was_measured_on(tmp_pa
     for arch, B, tag in (("IAN_simple", 64, "ian_simple_b64"), ("IAN", 256, "ian_b256")):
         v, src = bench.pmc_traffic(arch, B)           # the newest committed summary: quoted if it is this build's, else labelled
         newest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_%s.json" % tag))[-1]
-        fresh = json.load(open(os.path.join(ROOT, "profiles", newest))).get("csrc_digest") == build._digest()
+        fresh = json.load(open(os.path.join(ROOT, "profiles", newest))).get("csrc_digest") in (build._digest("inference"), build._digest())
         assert newest in src and ((v and v > 1e6) if fresh else (v is None and "stale" in src)), (v, src, fresh)
     assert bench.pmc_traffic("IAN_simple", 32) == (None, None)            # no committed profile for that workload
     (tmp_path / "profiles").mkdir()
@@ -354,7 +354,7 @@ def test_bench_quotes_pmc_traffic_only_for_the_sources_it_was_measured_on(tmp_pa
     (tmp_path / "profiles" / "r09_ian_simple_b64.json").write_text(json.dumps(stale))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     v, why = bench.pmc_traffic("IAN_simple", 64)
-    assert v is None and "stale" in why and build._digest()[:12] in why
-    stale["csrc_digest"] = build._digest()
+    assert v is None and "stale" in why and build._digest("inference")[:12] in why
+    stale["csrc_digest"] = build._digest("inference")     # training-only sources (kernels_train.hip, ian_trainer.cpp ...) do not enter
     (tmp_path / "profiles" / "r09_ian_simple_b64.json").write_text(json.dumps(stale))
     assert bench.pmc_traffic("IAN_simple", 64) == (1.0e8, os.path.join("profiles", "r09_ian_simple_b64.json"))
