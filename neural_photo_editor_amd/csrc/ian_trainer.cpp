@@ -142,10 +142,6 @@ struct ian_trainer {
   // backward-data chain; the compute stream joins before the regularisers.  Same launches, same per-parameter order.
   int overlap_wgrad = 1;
   hipStream_t st2 = nullptr;
-  // wgrad_low_priority (experiment): the same stream role at the LOWEST stream priority, so that when both queues hold ready
-  // workgroups the dispatcher serves the critical data-gradient chain first
-  hipStream_t st2_norm = nullptr, st2_low = nullptr;
-  int wgrad_low_priority = 0;
   std::vector<hipEvent_t> events;
   size_t ev_used = 0;
   hipStream_t last_stream = nullptr;               // stream of the previous entry: a different one is synchronised first
@@ -1176,19 +1172,10 @@ int ian_trainer_finalize(ian_trainer* t) {
   t->zgen = dalloc(t, (size_t)t->n * 128); t->zgen0 = dalloc(t, (size_t)t->n * 128);
   t->xin = dalloc(t, (size_t)t->n * 3 * 4096); t->zin = dalloc(t, (size_t)t->n * 100); t->epsin = dalloc(t, (size_t)t->n * 100);
   if (t->oom) return tfail(t, -20, "out of device memory while allocating the training step's buffers (batch %d per GPU)", t->n);
-  if (hipStreamCreateWithFlags(&t->st2_norm, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&t->st2, hipStreamNonBlocking) != hipSuccess) {
     (void)hipGetLastError();
-    t->st2_norm = nullptr;   // no second stream: weight gradients stay on the compute stream
+    t->st2 = nullptr;   // no second stream: weight gradients stay on the compute stream
   }
-  {
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
-        hipStreamCreateWithPriority(&t->st2_low, hipStreamNonBlocking, least) != hipSuccess) {
-      (void)hipGetLastError();
-      t->st2_low = nullptr;
-    }
-  }
-  t->st2 = (t->wgrad_low_priority && t->st2_low) ? t->st2_low : t->st2_norm;
   if (t->world > 1) THIP(hipStreamCreateWithFlags(&t->st_comm, hipStreamNonBlocking));
   if (t->exact && ((t->n & (t->n - 1)) || (t->world & (t->world - 1))))
     fprintf(stderr, "libian: per-rank batch %d x world %d is not a power of two: the partial-sum tree of the batch statistics associates "
@@ -1511,10 +1498,6 @@ int ian_trainer_set_option(ian_trainer* t, const char* key, double value) {
   if (k == "learning_rate") t->cfg.learning_rate = value;  // train_IAN.py:523-527 learning-rate schedule
   else if (k == "head6") t->head6 = value != 0.0;
   else if (k == "overlap_wgrad") t->overlap_wgrad = value != 0.0;
-  else if (k == "wgrad_low_priority") {      // between steps only: the previous step joined its weight-gradient stream
-    t->wgrad_low_priority = value != 0.0;
-    if (t->finalized) t->st2 = (t->wgrad_low_priority && t->st2_low) ? t->st2_low : t->st2_norm;
-  }
   else if (k == "update_running") t->update_running = value != 0.0;
   else if (k == "overlap") t->overlap = value != 0.0;                       // gradient buckets handed over during backward
   else if (k == "bucket_bytes") { t->bucket_bytes = (int64_t)value > 4 ? (int64_t)value : 4; t->plans.clear(); }
@@ -1535,8 +1518,7 @@ void ian_trainer_destroy(ian_trainer* t) {
   IAN_GUARD_CHECK("ian_trainer_destroy");
   (void)hipDeviceSynchronize();
   for (hipEvent_t e : t->events) (void)hipEventDestroy(e);
-  if (t->st2_norm) (void)hipStreamDestroy(t->st2_norm);
-  if (t->st2_low) (void)hipStreamDestroy(t->st2_low);
+  if (t->st2) (void)hipStreamDestroy(t->st2);
   if (t->st_comm) (void)hipStreamDestroy(t->st_comm);
   if (t->ex0) (void)hipEventDestroy(t->ex0);
   if (t->ex1) (void)hipEventDestroy(t->ex1);
