@@ -220,7 +220,8 @@ def test_training_functions_vs_reference_train_IAN():
     keep = [i for i, n in enumerate(fx["discrim/metric_names"].tolist()) if n != "discrim_acc"]
     _note("second_update_metric_rel_err", {n: float(abs(got[i] - fx["discrim/metrics"][i]) / max(1.0, abs(fx["discrim/metrics"][i])))
                                            for i, n in enumerate(fx["discrim/metric_names"].tolist())})
-    assert np.allclose(got[keep], fx["discrim/metrics"][keep], rtol=2e-3, atol=2e-3), (got, fx["discrim/metrics"])
+    # the second update starts from parameters that took one float32 Adam step: measured 4.7e-6 (round 4; round 3 allowed 1e-2)
+    assert np.allclose(got[keep], fx["discrim/metrics"][keep], rtol=2e-4, atol=2e-4), (got, fx["discrim/metrics"])
     assert tr.groups["Z"].t == 2 and tr.groups["dec"].t == 1 and tr.groups["enc"].t == 1     # ONE Adam instance for Z (:266-276)
     after = tr.params_numpy()
     moved, err = [], []
