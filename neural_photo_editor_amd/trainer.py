@@ -497,6 +497,8 @@ class Trainer:
         m = [np.ascontiguousarray(x, np.float32) for x in made.masks_once(self.zdim)]      # train_IAN.py:404-405
         self._check(self.lib.ian_trainer_set_made_masks(self._h, *[C.c_void_p(x.ctypes.data) for x in m], m[0].shape[0]))
         self._check(self.lib.ian_trainer_finalize(self._h))
+        if self.comm.world > 1 and getattr(self.comm, "bucket_bytes", None):
+            self.set_option("bucket_bytes", int(self.comm.bucket_bytes))       # Comm(bucket_bytes=...) sizes the C sequencer's buckets
         self.groups = {g: _Group(self, g) for g in ("enc", "Z", "dec")}
         self.where = {}
         gi, off, cnt = C.c_int32(), C.c_int64(), C.c_int64()
