@@ -218,6 +218,16 @@ typedef struct ian_comm_ops {
   int (*allgather)(void* ctx, const float* src, float* dst, int64_t count, void* stream);
 } ian_comm_ops;
 int ian_trainer_set_comm(ian_trainer* t, const ian_comm_ops* ops, int32_t exact);
+/* The table filled from librccl directly (csrc/ian_comm_rccl.cpp; librccl is dlopen'ed at the first call, libian.so does not link
+   it): the torch-free route for a C / C++ caller, one process per GPU.  Rank 0 obtains the 128-byte communicator id and hands it
+   to every rank out of band; every rank (after hipSetDevice) joins with the same bytes -- the call blocks until all `world` ranks
+   have arrived -- and passes the filled table to ian_trainer_set_comm.  allreduce_sum = ncclAllReduce (in place, float32, sum) on
+   the stream the trainer hands over, wait_all = an event behind the last all-reduce that the compute stream waits for on the
+   device, allgather = ncclAllGather.  0 / negative (-10: librccl could not be loaded), text via ian_rccl_last_error. */
+int ian_rccl_unique_id(void* out128);
+int ian_rccl_comm_create(const void* id128, int32_t rank, int32_t world, ian_comm_ops* ops);
+void ian_rccl_comm_destroy(ian_comm_ops* ops);
+const char* ian_rccl_last_error(void);
 /* GANcheckpoints.py:33-57: one call per npz entry, Theano parameter names (trainable parameters, "<bn>.mean|inv_std",
    "l_IAF_{mu,ls}_{input,output_W,output_D}.{W,b}"); host pointer. */
 int ian_trainer_load_param(ian_trainer* t, const char* name, const float* data, int64_t numel);

@@ -14,7 +14,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["kernels_tapgemm.hip", "kernels_misc.hip", "kernels_head.hip", "kernels_npe.hip", "kernels_wgrad.hip", "kernels_train.hip", "ian_runtime.cpp", "ian_train_abi.cpp", "ian_trainer.cpp"]
+SOURCES = ["kernels_tapgemm.hip", "kernels_misc.hip", "kernels_head.hip", "kernels_npe.hip", "kernels_wgrad.hip", "kernels_train.hip", "ian_runtime.cpp", "ian_train_abi.cpp", "ian_trainer.cpp", "ian_comm_rccl.cpp"]
 HEADERS = ["ian_internal.h", "ian_guard.h", "ian_rt_types.h", "ian_rt_util.inc", "ian_rt_pack.inc", "ian_rt_schedule.inc", "ian_rt_exec.inc",
            "ian_rt_autotune.inc", "ian_rt_io.inc", "ian_rt_backward.inc", "ian_rt_edit.inc", "ian_rt_api.inc", "ian_rt_layer.inc", os.path.join("..", "..", "include", "ian.h"), os.path.join("..", "..", "include", "ian_train.h")]
 # IAN_ABLATION_BUILD=1 (tests/test_gpu_ablation.py, scripts/ablate_tapgemm.sh): a SEPARATE library, libian_ablation.so, with
@@ -30,7 +30,7 @@ if ABLATION:
 SANITIZE = bool(os.environ.get("IAN_SANITIZE")) and not ABLATION
 LIB = os.path.join(HERE, "libian_ablation.so" if ABLATION else ("libian_asan.so" if SANITIZE else "libian.so"))
 STAMP = os.path.join(HERE, ".libian_ablation.stamp" if ABLATION else (".libian_asan.stamp" if SANITIZE else ".libian.stamp"))
-HOST_SOURCES = ("ian_runtime.cpp", "ian_train_abi.cpp", "ian_trainer.cpp")
+HOST_SOURCES = ("ian_runtime.cpp", "ian_train_abi.cpp", "ian_trainer.cpp", "ian_comm_rccl.cpp")
 # The host units contain no device code (they call the launch_* wrappers of the .hip files), so the sanitized build compiles
 # them with g++ against the HIP runtime API: GCC's ASan runtime, unlike ROCm clang's, does not intercept the HSA allocator
 # (under the ROCm one every process that touches the GPU dies in hsa_amd_memory_pool_allocate on this image).
@@ -59,7 +59,7 @@ def _hipcc():
 
 
 # sources that only the training step uses: a change there cannot alter a reconstruction / brush kernel
-TRAINING_ONLY = ("kernels_train.hip", "kernels_wgrad.hip", "ian_train_abi.cpp", "ian_trainer.cpp", "ian_rt_layer.inc",
+TRAINING_ONLY = ("kernels_train.hip", "kernels_wgrad.hip", "ian_train_abi.cpp", "ian_trainer.cpp", "ian_comm_rccl.cpp", "ian_rt_layer.inc",
                  os.path.join("..", "..", "include", "ian_train.h"))
 
 

@@ -127,6 +127,36 @@ class Comm:
             self.dist.all_gather(list(out.chunk(self.world, dim=0)), local.contiguous(), group=self.group)
 
 
+class NativeRcclComm(Comm):
+    """The same data-parallel step with the collective table filled by libian itself from librccl (csrc/ian_comm_rccl.cpp:
+    ncclAllReduce / ncclAllGather on the trainer's streams) -- the route a C caller takes; torch.distributed is used ONCE, to hand
+    rank 0's 128-byte communicator id to the other ranks.  One GPU per rank (RCCL refuses two ranks on one device), so the
+    shared-GPU gloo tests cannot drive it: covered at world size 1 (tests/test_gpu_dp.py) and by construction."""
+
+    def ops(self, torch):
+        lib = load_train_library()
+        ident = C.create_string_buffer(128)
+        if self.rank == 0:
+            rc = lib.ian_rccl_unique_id(ident)
+            if rc:
+                raise IanTrainError("ian_rccl_unique_id failed (%d): %s" % (rc, (lib.ian_rccl_last_error() or b"?").decode()))
+        if self.world > 1:
+            box = [ident.raw]
+            self.dist.broadcast_object_list(box, src=0, group=self.group)
+            ident = C.create_string_buffer(box[0], 128)
+        o = CommOps()
+        rc = lib.ian_rccl_comm_create(ident, self.rank, self.world, C.byref(o))
+        if rc:
+            raise IanTrainError("ian_rccl_comm_create failed (%d): %s" % (rc, (lib.ian_rccl_last_error() or b"?").decode()))
+        self.errors, self._lib, self._native_ops = [], lib, o
+        return o
+
+    def close(self):
+        if getattr(self, "_native_ops", None) is not None:
+            self._lib.ian_rccl_comm_destroy(C.byref(self._native_ops))
+            self._native_ops = None
+
+
 # ======================================================================================================
 # thin wrappers over the C ABI
 # ======================================================================================================

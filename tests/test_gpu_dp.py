@@ -164,6 +164,38 @@ def test_batch_statistics_are_bitwise_rank_order_invariant():
         assert np.allclose(got[C:], (ref ** 2).sum(0), rtol=1e-13, atol=0)
 
 
+def test_native_rccl_collective_table_single_rank():
+    """csrc/ian_comm_rccl.cpp: the ian_comm_ops table filled from librccl itself (dlopen), exercised as far as ONE GPU allows: a
+    1-rank communicator whose all-reduce and all-gather are identities on the trainer's kind of buffers and streams, wait_all
+    orders a compute stream behind the side stream the all-reduce ran on, and the table is accepted by ian_trainer_set_comm.
+    (RCCL refuses two ranks on one device: the multi-rank step is covered with the torch.distributed filler over gloo above.)"""
+    import ctypes as C
+    import torch
+    from neural_photo_editor_amd import trainer as T
+    comm = T.NativeRcclComm()
+    assert comm.world == 1
+    ops = comm.ops(torch)
+    try:
+        assert (ops.world, ops.rank) == (1, 0) and ops.ctx
+        side, main = torch.cuda.Stream(), torch.cuda.current_stream()
+        x = torch.randn(1 << 20, device="cuda")
+        want = x.clone()
+        torch.cuda.synchronize()
+        assert ops.allreduce_sum(ops.ctx, x.data_ptr(), x.numel(), side.cuda_stream) == 0      # sum over one rank
+        assert ops.wait_all(ops.ctx, main.cuda_stream) == 0
+        y = x * 2                                                                                  # ordered behind the collective
+        torch.cuda.synchronize()
+        assert torch.equal(x, want) and torch.equal(y, want * 2)
+        dst = torch.zeros_like(x)
+        assert ops.allgather(ops.ctx, x.data_ptr(), dst.data_ptr(), x.numel(), main.cuda_stream) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(dst, want)
+        assert ops.allreduce_sum(ops.ctx, 0, 16, 0) != 0                                           # null buffer: an error code, no crash
+    finally:
+        comm.close()
+    assert ops.ctx is None
+
+
 def _diag(name, obj):
     """Measured error levels go to gpurun_out/diag/<name>.json so that bars can be tightened from evidence."""
     import json
