@@ -161,11 +161,12 @@ def train_step_bench(batch, rank, world, iters=3):
     at every world size: ian_train_step (csrc/ian_trainer.cpp); at N > 1 its collectives arrive through the ian_comm_ops
     table filled from torch.distributed (RCCL), SyncBN + MinibatchLayer all-gather on ("exact")."""
     import torch
-    from neural_photo_editor_amd.trainer import Trainer, Comm
+    from neural_photo_editor_amd.trainer import Trainer, default_comm
     from neural_photo_editor_amd import synthetic as O
     P = O.make_train_params(O.make_params("IAN", 1))
     cfg_path = os.path.join(ROOT, "neural_photo_editor_amd", "configs", "IAN.py")
-    tr = Trainer(cfg_path, P, batch=batch, comm=Comm(), exact=True)
+    comm = default_comm()      # N > 1 on RCCL: the torch-free librccl filler (csrc/ian_comm_rccl.cpp); falls back to torch.distributed
+    tr = Trainer(cfg_path, P, batch=batch, comm=comm, exact=True)
     rs = np.random.RandomState(50 + rank)
     X = torch.from_numpy(O.make_images(batch, seed=200 + rank)).cuda()
     Z = torch.from_numpy(rs.randn(batch, 100).astype(np.float32)).cuda()
@@ -186,8 +187,10 @@ def train_step_bench(batch, rank, world, iters=3):
             tr.step(which, X, Z, eps, return_metrics=False)
         torch.cuda.synchronize()
         out["update_%s_ms" % which] = (time.perf_counter() - t) / iters * 1e3
-        if world > 1:   # compute-stream stall on the gradient all-reduce (what backward did not hide), mean per update of this kind
+        if world > 1:   # compute-stream stall at wait_all (the part of the gradient all-reduce backward did not hide -- that stall ONLY),
+                        # and the time the compute stream spends inside the exact-mode all-gathers; means per update of this kind
             out.setdefault("allreduce_exposed_ms", {})[which] = tr.allreduce_exposed_ms()[which]
+            out.setdefault("allgather_ms", {})[which] = tr.allgather_ms()[which]
     pair = out["update_gen_ms"] + out["update_discrim_ms"]
     flops = batch * (TRAIN_FLOP_PER_IMAGE["gen"] + TRAIN_FLOP_PER_IMAGE["discrim"])
     ach = flops / (pair * 1e-3) / 1e12
@@ -203,7 +206,8 @@ def train_step_bench(batch, rank, world, iters=3):
                                 "dp%d, %s all-reduce of flat gradient groups in 16 MB buckets overlapped with backward, SyncBN statistics + "
                                 "MinibatchLayer all-gather (exact)"
                                 % (world, "RCCL" if os.environ.get("IAN_BENCH_BACKEND", "nccl") == "nccl" else os.environ["IAN_BENCH_BACKEND"] + " (test backend)")),
-                "entry": "ian_train_step (C, csrc/ian_trainer.cpp)%s" % ("" if world == 1 else "; collectives through ian_comm_ops <- torch.distributed"),
+                "entry": "ian_train_step (C, csrc/ian_trainer.cpp)%s" % ("" if world == 1 else "; collectives through ian_comm_ops <- " + comm.filler),
+                "collectives": None if world == 1 else comm.filler,
                 "note": "one update_gen + one update_discrim (strict alternation, train_IAN.py:497-504) over synthetic data"})
     tr.close()
     return out

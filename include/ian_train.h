@@ -104,6 +104,11 @@ int ian_k_tree_sum(const double* partial, int32_t count, int32_t width, double* 
 /* batch statistics -> mean, inv_std = 1/sqrt(var+eps), scale = gamma*inv_std, shift = beta - mean*scale */
 int ian_k_bn_make_affine(const double* sums, float count, float eps, const float* gamma, const float* beta, int32_t C,
                          float* mean, float* inv_std, float* scale, float* shift, void* stream);
+/* running averages of one normalisation, in place: r <- keep*r + alpha*batch for mean and inv_std in one launch (lasagne
+   BatchNormLayer alpha = 0.1); the same arithmetic as the fused ian_k_bn_stats_affine below, bit for bit -- what the data-parallel
+   `exact` step calls after ian_k_bn_make_affine */
+int ian_k_bn_running(float* run_mean, const float* mean, float* run_inv_std, const float* inv_std, int32_t C, float keep, float alpha,
+                     void* stream);
 /* Single-process forms of the two-stage statistics above (no collective between the stages): the same chunk sums and the same
    tree, finished in ONE launch.  Bit-identical to ian_k_colstats + ian_k_bn_make_affine (+ the running-average updates
    r = keep*r + alpha*batch of lasagne BatchNormLayer, alpha = 0.1; run_mean/run_inv_std NULL: none), resp. to
@@ -222,10 +227,15 @@ int ian_trainer_set_comm(ian_trainer* t, const ian_comm_ops* ops, int32_t exact)
    it): the torch-free route for a C / C++ caller, one process per GPU.  Rank 0 obtains the 128-byte communicator id and hands it
    to every rank out of band; every rank (after hipSetDevice) joins with the same bytes -- the call blocks until all `world` ranks
    have arrived -- and passes the filled table to ian_trainer_set_comm.  allreduce_sum = ncclAllReduce (in place, float32, sum) on
-   the stream the trainer hands over, wait_all = an event behind the last all-reduce that the compute stream waits for on the
-   device, allgather = ncclAllGather.  0 / negative (-10: librccl could not be loaded), text via ian_rccl_last_error. */
+   the stream the trainer hands over, wait_all = one event per distinct stream an all-reduce was issued on since the last wait,
+   which the compute stream waits for on the device, allgather = ncclAllGather.  ian_rccl_comm_add_gather (optional, a second id
+   from ian_rccl_unique_id, every rank, blocks like comm_create) gives the all-gathers their OWN communicator: one communicator
+   runs its collectives in issue order whatever streams they are on, so without it a batch-statistics all-gather the compute
+   stream blocks on queues behind every gradient bucket already handed over.  0 / negative (-10: librccl could not be loaded),
+   text via ian_rccl_last_error. */
 int ian_rccl_unique_id(void* out128);
 int ian_rccl_comm_create(const void* id128, int32_t rank, int32_t world, ian_comm_ops* ops);
+int ian_rccl_comm_add_gather(ian_comm_ops* ops, const void* id128);
 void ian_rccl_comm_destroy(ian_comm_ops* ops);
 const char* ian_rccl_last_error(void);
 /* GANcheckpoints.py:33-57: one call per npz entry, Theano parameter names (trainable parameters, "<bn>.mean|inv_std",
@@ -238,7 +248,9 @@ int ian_trainer_finalize(ian_trainer* t);
    [-1,1], zrand (n,100) ~ N(0,1) (:478), eps (n,100) = the GaussianSampleLayer draw (layers.py:433): host or device
    pointers.  metrics: NULL, or 9 HOST floats of THIS minibatch before the update = discrim_d_loss, gen_recon_loss,
    gen_sample_loss, discrim_g_loss, discrim_acc, kl_div, pixel_loss, pixel_acc, feature_loss (train_IAN.py:291-304; reading
-   them synchronises `stream`).  0 / negative, text via ian_trainer_last_error. */
+   them synchronises `stream`).  Data parallel: the 64-float all-reduce of the loss partials is issued on EVERY step whether or
+   not `metrics` is given, so ranks may disagree on that argument without their collective sequences diverging.
+   0 / negative, text via ian_trainer_last_error. */
 int ian_train_step(ian_trainer* t, int32_t which, const float* x, const float* zrand, const float* eps, int32_t n, float* metrics,
                    void* stream);
 /* The same step in pieces, for tests and diagnostics (ian_train_step == forward, [metrics], backward, finish_allreduce,
@@ -266,7 +278,10 @@ int ian_trainer_group(ian_trainer* t, int32_t group, float** p, float** g, float
 int ian_trainer_param_info(ian_trainer* t, const char* name, int32_t* group, int64_t* offset, int64_t* numel);
 /* parameters of `group` were written behind the trainer's back: repack before the next forward */
 int ian_trainer_mark_dirty(ian_trainer* t, int32_t group);
-/* "exposed_ms_gen|discrim" (mean stall of the compute stream on the gradient all-reduce, option measure_exposed),
+/* option measure_exposed: "exposed_ms_gen|discrim" = mean stall of the compute stream at wait_all per update (the part of the
+   gradient all-reduce backward did not hide -- the wait_all stall ONLY), "gather_ms_gen|discrim" = mean time per update the
+   compute stream spends inside the exact-mode all-gathers (batch statistics, MinibatchLayer; includes any queueing behind
+   gradient buckets when the backend runs both on one communicator), "gathers_gen|discrim" = their number per update;
    "plan_buckets_gen|discrim", "overlap_log", "world", "rank", "exact", "global_batch" */
 int ian_trainer_stat(ian_trainer* t, const char* key, double* out);
 /* rec[6] = which, group, first element, bytes, gradient write after which the bucket was handed over, writes of that sweep */
@@ -280,7 +295,7 @@ int ian_trainer_read_param(ian_trainer* t, const char* name, int32_t grad, float
    "measure_exposed";
    "learning_rate" (schedule, train_IAN.py:523-527), "head6", "update_running"; "overlap_wgrad" (default 1): weight-gradient
    GEMMs go to a second HIP stream owned by the trainer and are joined before the regularizers and Adam -- same launches, same
-   numbers, bitwise (tests/test_gpu_ctrainer.py); 0 keeps everything on the caller's stream */
+   numbers, bitwise (tests/test_gpu_train_step.py); 0 keeps everything on the caller's stream */
 int ian_trainer_set_option(ian_trainer* t, const char* key, double value);
 /* Adam step counter of group 0 = encoder_params, 1 = Z_params (stepped by BOTH updates, train_IAN.py:274-276), 2 = decoder_params */
 int32_t ian_trainer_adam_steps(ian_trainer* t, int32_t group);

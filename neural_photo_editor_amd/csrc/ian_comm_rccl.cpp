@@ -1,69 +1,85 @@
 // ian_comm_rccl: the collective table of the training step (ian_comm_ops, include/ian_train.h) filled from librccl directly --
 // what a C / C++ caller of ian_train_step uses for the data-parallel step (north_star: RCCL gradient all-reduce over xGMI,
-// one process per GPU).  The Python host fills the same table from torch.distributed (trainer.Comm.ops), whose "nccl" backend
-// IS RCCL; this file is the torch-free route.  RCCL collectives are stream-ordered:
+// one process per GPU), and since round 5 what bench.py / train_cli.py use at N > 1 (trainer.NativeRcclComm; the
+// torch.distributed filler trainer.Comm.ops is the fallback).  RCCL collectives are stream-ordered:
 //   allreduce_sum -> ncclAllReduce(in place, float32, sum) on the stream the trainer hands over (its side stream),
-//   wait_all      -> an event recorded behind the last all-reduce, the given (compute) stream waits for it on the device,
-//   allgather     -> ncclAllGather on the given stream.
-// librccl is resolved with dlopen at the first call, not linked: libian.so loads (and every single-GPU path runs) on hosts
-// without it, and a process that already maps an RCCL (PyTorch-ROCm ships one) reuses that copy.
-// The 128-byte unique id travels out of band (whatever the launcher has: a file, MPI, a torch.distributed store): rank 0 calls
-// ian_rccl_unique_id, every rank calls ian_rccl_comm_create with the same bytes.
+//   wait_all      -> one event per DISTINCT stream an all-reduce was issued on since the last wait, the given (compute) stream
+//                    waits for each of them on the device,
+//   allgather     -> ncclAllGather on the given stream, on a SECOND communicator when one was added (ian_rccl_comm_add_gather):
+//                    one communicator serialises its collectives in issue order whatever streams they are on, so a 16 MB gradient
+//                    bucket handed over during backward would sit in front of the next batch-statistics all-gather the compute
+//                    stream blocks on; with its own communicator the small all-gather overtakes the bucket.
+// librccl is resolved with dlopen at the first call, not linked, and NOTHING of <rccl/rccl.h> is needed to build this file (the
+// seven prototypes below are RCCL's stable NCCL-compatible C ABI): libian.so builds and loads -- and every single-GPU path runs
+// -- on hosts without RCCL, and a process that already maps an RCCL (PyTorch-ROCm ships one) reuses that copy.
+// The 128-byte unique ids travel out of band (whatever the launcher has: a file, MPI, a torch.distributed store): rank 0 calls
+// ian_rccl_unique_id (once per communicator), every rank calls ian_rccl_comm_create [+ ian_rccl_comm_add_gather] with the same bytes.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/ian_train.h"
 
 namespace {
 
+// ---- the slice of the NCCL / RCCL C ABI this file calls (rccl.h: ncclUniqueId is 128 opaque bytes passed BY VALUE,
+// ncclSuccess = 0, ncclFloat32 = 7, ncclSum = 0) ------------------------------------------------------------------------
+constexpr int kIdBytes = 128;
+struct RcclUniqueId { char internal[kIdBytes]; };
+typedef struct ncclComm* RcclComm;
+typedef int RcclResult;
+constexpr int kRcclSuccess = 0, kRcclFloat32 = 7, kRcclSum = 0;
+
 thread_local std::string g_rccl_err;
 
 struct Api {
   void* lib = nullptr;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  const char* (*GetErrorString)(ncclResult_t) = nullptr;
-  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  RcclResult (*GetUniqueId)(RcclUniqueId*) = nullptr;
+  RcclResult (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
+  RcclResult (*CommDestroy)(RcclComm) = nullptr;
+  const char* (*GetErrorString)(RcclResult) = nullptr;
+  RcclResult (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+  RcclResult (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
 };
 
 Api* api() {
   static Api a;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  static std::once_flag once;   // two threads creating communicators at the same time resolve the library once
+  std::call_once(once, [] {
     // the soname first: a process that already maps an RCCL under it (PyTorch-ROCm) gets that copy back; RTLD_LOCAL: our handle
     // only, nothing of it enters the global symbol scope
     for (const char* name : {"librccl.so.1", "librccl.so"}) {
       a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (a.lib) break;
     }
-    if (a.lib) {
-      a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.lib, "ncclGetUniqueId");
-      a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.lib, "ncclCommInitRank");
-      a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
-      a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
-      a.AllReduce = (decltype(a.AllReduce))dlsym(a.lib, "ncclAllReduce");
-      a.AllGather = (decltype(a.AllGather))dlsym(a.lib, "ncclAllGather");
-      if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.GetErrorString || !a.AllReduce || !a.AllGather) a.lib = nullptr;
-    }
-  }
+    if (!a.lib) return;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.lib, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.lib, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(a.lib, "ncclAllReduce");
+    a.AllGather = (decltype(a.AllGather))dlsym(a.lib, "ncclAllGather");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.GetErrorString || !a.AllReduce || !a.AllGather) a.lib = nullptr;
+  });
   return a.lib ? &a : nullptr;
 }
 
 struct Ctx {
-  ncclComm_t comm = nullptr;
-  hipEvent_t ev = nullptr;
-  hipStream_t last = nullptr;   // stream of the most recent allreduce_sum since the last wait_all
-  bool pending = false;
+  RcclComm comm = nullptr;      // gradient all-reduces
+  RcclComm gather = nullptr;    // batch-statistics / MinibatchLayer all-gathers (nullptr: they share `comm`)
+  int world = 1, rank = 0;
+  // streams an all-reduce was issued on since the last wait_all, each with its own event (a caller with two side streams gets
+  // both waited for; the trainer uses one)
+  std::vector<std::pair<hipStream_t, hipEvent_t>> pending;
+  std::vector<hipEvent_t> free_events;
 };
 
-int fail(const char* what, ncclResult_t r) {
+int fail(const char* what, RcclResult r) {
   Api* a = api();
   g_rccl_err = std::string(what) + ": " + (a ? a->GetErrorString(r) : "librccl not loaded");
   return 1;
@@ -73,31 +89,45 @@ int cb_allreduce(void* c, float* buf, int64_t count, void* stream) {
   Ctx* x = (Ctx*)c;
   Api* a = api();
   if (!x || !a || !buf || count <= 0) return 1;
-  const ncclResult_t r = a->AllReduce(buf, buf, (size_t)count, ncclFloat, ncclSum, x->comm, (hipStream_t)stream);
-  if (r != ncclSuccess) return fail("ncclAllReduce", r);
-  x->last = (hipStream_t)stream;
-  x->pending = true;
+  const hipStream_t st = (hipStream_t)stream;
+  const RcclResult r = a->AllReduce(buf, buf, (size_t)count, kRcclFloat32, kRcclSum, x->comm, st);
+  if (r != kRcclSuccess) return fail("ncclAllReduce", r);
+  for (auto& p : x->pending)
+    if (p.first == st) return 0;
+  hipEvent_t e = nullptr;
+  if (!x->free_events.empty()) {
+    e = x->free_events.back();
+    x->free_events.pop_back();
+  } else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    g_rccl_err = "hipEventCreateWithFlags failed in allreduce_sum";
+    return 1;
+  }
+  x->pending.push_back({st, e});
   return 0;
 }
 int cb_wait_all(void* c, void* stream) {
   Ctx* x = (Ctx*)c;
   if (!x) return 1;
-  if (!x->pending) return 0;
-  x->pending = false;
-  if (x->last == (hipStream_t)stream) return 0;            // same stream: already ordered
-  if (hipEventRecord(x->ev, x->last) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, x->ev, 0) != hipSuccess) {
-    g_rccl_err = "hipEventRecord / hipStreamWaitEvent failed in wait_all";
-    (void)hipGetLastError();
-    return 1;
+  int rc = 0;
+  for (auto& p : x->pending) {
+    if (p.first != (hipStream_t)stream &&            // the same stream is already ordered
+        (hipEventRecord(p.second, p.first) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, p.second, 0) != hipSuccess)) {
+      g_rccl_err = "hipEventRecord / hipStreamWaitEvent failed in wait_all";
+      (void)hipGetLastError();
+      rc = 1;
+    }
+    x->free_events.push_back(p.second);
   }
-  return 0;
+  x->pending.clear();
+  return rc;
 }
 int cb_allgather(void* c, const float* src, float* dst, int64_t count, void* stream) {
   Ctx* x = (Ctx*)c;
   Api* a = api();
   if (!x || !a || !src || !dst || count <= 0) return 1;
-  const ncclResult_t r = a->AllGather(src, dst, (size_t)count, ncclFloat, x->comm, (hipStream_t)stream);
-  if (r != ncclSuccess) return fail("ncclAllGather", r);
+  const RcclResult r = a->AllGather(src, dst, (size_t)count, kRcclFloat32, x->gather ? x->gather : x->comm, (hipStream_t)stream);
+  if (r != kRcclSuccess) return fail("ncclAllGather", r);
   return 0;
 }
 
@@ -115,10 +145,10 @@ int ian_rccl_unique_id(void* out128) {
     g_rccl_err = "librccl.so could not be loaded (dlopen)";
     return -10;
   }
-  ncclUniqueId id;
-  const ncclResult_t r = a->GetUniqueId(&id);
-  if (r != ncclSuccess) return -fail("ncclGetUniqueId", r);
-  memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
+  RcclUniqueId id;
+  const RcclResult r = a->GetUniqueId(&id);
+  if (r != kRcclSuccess) return -fail("ncclGetUniqueId", r);
+  memcpy(out128, id.internal, kIdBytes);
   return 0;
 }
 
@@ -131,20 +161,15 @@ int ian_rccl_comm_create(const void* id128, int32_t rank, int32_t world, ian_com
     g_rccl_err = "librccl.so could not be loaded (dlopen)";
     return -10;
   }
-  ncclUniqueId id;
-  memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+  RcclUniqueId id;
+  memcpy(id.internal, id128, kIdBytes);
   Ctx* x = new Ctx();
-  const ncclResult_t r = a->CommInitRank(&x->comm, world, id, rank);
-  if (r != ncclSuccess) {
+  x->world = world;
+  x->rank = rank;
+  const RcclResult r = a->CommInitRank(&x->comm, world, id, rank);
+  if (r != kRcclSuccess) {
     delete x;
     return -fail("ncclCommInitRank", r);
-  }
-  if (hipEventCreateWithFlags(&x->ev, hipEventDisableTiming) != hipSuccess) {
-    (void)hipGetLastError();
-    (void)a->CommDestroy(x->comm);
-    delete x;
-    g_rccl_err = "hipEventCreateWithFlags failed";
-    return -20;
   }
   memset(ops, 0, sizeof *ops);
   ops->world = world;
@@ -156,12 +181,32 @@ int ian_rccl_comm_create(const void* id128, int32_t rank, int32_t world, ian_com
   return 0;
 }
 
+/* optional, every rank, after ian_rccl_comm_create: a second communicator (its own id from ian_rccl_unique_id) that carries the
+   all-gathers, so that they are not queued behind gradient buckets in flight on the first one.  Blocks like comm_create. */
+int ian_rccl_comm_add_gather(ian_comm_ops* ops, const void* id128) {
+  Api* a = api();
+  if (!ops || !ops->ctx || !id128 || ops->allgather != cb_allgather) return -1;
+  if (!a) return -10;
+  Ctx* x = (Ctx*)ops->ctx;
+  if (x->gather) return -6;
+  RcclUniqueId id;
+  memcpy(id.internal, id128, kIdBytes);
+  const RcclResult r = a->CommInitRank(&x->gather, x->world, id, x->rank);
+  if (r != kRcclSuccess) {
+    x->gather = nullptr;
+    return -fail("ncclCommInitRank (gather communicator)", r);
+  }
+  return 0;
+}
+
 /* after ian_trainer_destroy of every trainer that used the table */
 void ian_rccl_comm_destroy(ian_comm_ops* ops) {
   if (!ops || !ops->ctx) return;
   Ctx* x = (Ctx*)ops->ctx;
   Api* a = api();
-  if (x->ev) (void)hipEventDestroy(x->ev);
+  for (auto& p : x->pending) (void)hipEventDestroy(p.second);
+  for (hipEvent_t e : x->free_events) (void)hipEventDestroy(e);
+  if (a && x->gather) (void)a->CommDestroy(x->gather);
   if (a && x->comm) (void)a->CommDestroy(x->comm);
   delete x;
   ops->ctx = nullptr;

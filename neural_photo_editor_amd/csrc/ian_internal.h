@@ -342,6 +342,8 @@ hipError_t launch_bn_bwd_stats(const ColStatsArgs& a, int nchunks, double* sums,
 hipError_t launch_tree_sum(const double* partial, int count, int width, double* out, hipStream_t s);
 hipError_t launch_bn_make_affine(const double* sums, float count, float eps, const float* gamma, const float* beta,
                                  int C, float* mean, float* inv_std, float* scale, float* shift, hipStream_t s);
+hipError_t launch_bn_running(float* run_mean, const float* mean, float* run_inv_std, const float* inv_std, int C, float keep,
+                             float alpha, hipStream_t s);
 struct BnBwdArgs {
   const float* dA;
   const float* a;

@@ -52,6 +52,12 @@ int ian_k_bn_make_affine(const double* sums, float count, float eps, const float
   return chk(launch_bn_make_affine(sums, count, eps, gamma, beta, C, mean, inv_std, scale, shift, ST), "ian_k_bn_make_affine");
 }
 
+int ian_k_bn_running(float* run_mean, const float* mean, float* run_inv_std, const float* inv_std, int32_t C, float keep, float alpha,
+                     void* stream) {
+  if (!run_mean || !mean || !run_inv_std || !inv_std || C <= 0) return bad("ian_k_bn_running");
+  return chk(launch_bn_running(run_mean, mean, run_inv_std, inv_std, C, keep, alpha, ST), "ian_k_bn_running");
+}
+
 int ian_k_bn_stats_affine(const float* y, int64_t rows, int32_t C, int32_t stride, double* workspace, int32_t nchunks, double* sums,
                           float count, float eps, const float* gamma, const float* beta, float* mean, float* inv_std, float* scale,
                           float* shift, float* run_mean, float* run_inv_std, float keep, float alpha, void* stream) {

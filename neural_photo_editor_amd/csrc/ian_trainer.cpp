@@ -164,6 +164,13 @@ struct ian_trainer {
   int ex_which = 0;
   double exposed_ms[2] = {0, 0};
   int exposed_n[2] = {0, 0};
+  // measure_exposed: time the compute stream spends inside the exact-mode all-gathers (event pairs around every comm.allgather).
+  // Two pools used by alternate steps: a pool is folded (its events completed a whole step ago) right before it is reused.
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> gev[2];
+  size_t gev_used[2] = {0, 0};
+  int gev_which[2] = {0, 0}, gpar = 0;
+  double gather_ms[2] = {0, 0}, gather_calls[2] = {0, 0};
+  int gather_n[2] = {0, 0};
   const float *xhat_override = nullptr, *xgen_override = nullptr;   // test hook of ian_trainer_forward
 };
 
@@ -378,6 +385,13 @@ void z_alloc(ian_trainer* t) {
     Z[std::string("y_") + nm] = dalloc(t, n * 128); Z[nm] = dalloc(t, n * 128); Z[std::string("d") + nm] = dalloc(t, n * 128);
     t->bnZ[std::string("bn_") + nm] = make_bn(t, t->cfg.num_latents);
   }
+  {  // the two latent normalisations read the same input in the same stage: their float64 sums lie side by side so that the
+     // data-parallel `exact` step combines both with ONE all-gather per direction (z_forward / z_backward)
+    const int Zd = t->cfg.num_latents;
+    double *js = dalloc64(t, 4 * Zd), *jb = dalloc64(t, 4 * Zd);
+    t->bnZ["bn_mu"].sums = js; t->bnZ["bn_ls"].sums = js ? js + 2 * Zd : nullptr;
+    t->bnZ["bn_mu"].bsums = jb; t->bnZ["bn_ls"].bsums = jb ? jb + 2 * Zd : nullptr;
+  }
   Z["z0"] = dalloc(t, n * 128); Z["z"] = dalloc(t, n * 128); Z["dz0"] = dalloc(t, n * 128); Z["kl"] = dalloc(t, n * 100);
 }
 void dec_alloc(ian_trainer* t, Bufs& D, std::map<std::string, BN>& bn) {
@@ -520,7 +534,15 @@ std::vector<Bucket> make_plan(ian_trainer* t, int which) {  // buckets of the gr
   }
   return plan;
 }
+int join_side_stream(ian_trainer* t);
 int begin_backward(ian_trainer* t, int which) {
+  // every event handed out so far has been consumed by a hipStreamWaitEvent already issued: the pool restarts here whether or not
+  // the weight-gradient stream is in use (with overlap_wgrad = 0 nothing else reset it and a data-parallel run grew it by one
+  // event per bucket per step)
+  int jrc = join_side_stream(t);
+  if (jrc) return jrc;
+  t->ev_used = 0;
+  t->gev_which[t->gpar] = which;
   t->touched.clear();
   t->evlog.clear();
   t->which_now = which;
@@ -543,7 +565,6 @@ int begin_backward(ian_trainer* t, int which) {
     }
   return 0;
 }
-int join_side_stream(ian_trainer* t);
 int finish_allreduce(ian_trainer* t, int which) {  // after backward: reduce what has not been handed over yet, then the compute stream waits
   int rc;
   if ((rc = join_side_stream(t))) return rc;
@@ -582,6 +603,44 @@ int finish_allreduce(ian_trainer* t, int which) {  // after backward: reduce wha
   t->buckets = nullptr;
   return 0;
 }
+// every exact-mode all-gather goes through here (batch statistics, MinibatchLayer activations / gradients): issued on the COMPUTE
+// stream, whose next kernel reads the result.  measure_exposed: an event pair around it, folded a step later (fold_gathers).
+int gather(ian_trainer* t, const float* src, float* dst, int64_t count, const char* what) {
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  if (t->measure_exposed) {
+    auto& pool = t->gev[t->gpar];
+    if (t->gev_used[t->gpar] == pool.size()) {
+      hipEvent_t a, b;
+      THIP(hipEventCreate(&a));
+      THIP(hipEventCreate(&b));
+      pool.push_back({a, b});
+    }
+    ev = &pool[t->gev_used[t->gpar]++];
+    THIP(hipEventRecord(ev->first, t->st));
+  }
+  const int rc = t->comm.allgather(t->comm.ctx, src, dst, count, t->st);
+  if (rc) return tfail(t, -30, "comm.allgather failed (%d) on %s", rc, what);
+  if (ev) THIP(hipEventRecord(ev->second, t->st));
+  return 0;
+}
+void fold_gathers(ian_trainer* t, int par) {   // events of pool `par` completed long ago (a whole step), or the caller synchronised
+  double ms_total = 0.0;
+  const size_t n = t->gev_used[par];
+  for (size_t i = 0; i < n; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(t->gev[par][i].second) == hipSuccess && hipEventElapsedTime(&ms, t->gev[par][i].first, t->gev[par][i].second) == hipSuccess)
+      ms_total += ms;
+  }
+  (void)hipGetLastError();
+  if (n) {
+    const int w = t->gev_which[par];
+    t->gather_ms[w] += ms_total;
+    t->gather_calls[w] += (double)n;
+    t->gather_n[w] += 1;
+  }
+  t->gev_used[par] = 0;
+}
+
 // sums (float64 [width]) <- sum over ranks, combined in RANK ORDER by the pairwise tree of ian_k_tree_sum: the result does not depend
 // on the collective's internal algorithm and, for power-of-two shards, equals the single-process reduction bit for bit (SyncBN)
 int allreduce_ordered(ian_trainer* t, double* sums, int width) {
@@ -593,8 +652,8 @@ int allreduce_ordered(ian_trainer* t, double* sums, int width) {
     t->gbuf = p;
     t->gbuf_cap = need;
   }
-  const int rc = t->comm.allgather(t->comm.ctx, reinterpret_cast<const float*>(sums), reinterpret_cast<float*>(t->gbuf), 2 * (int64_t)width, t->st);
-  if (rc) return tfail(t, -30, "comm.allgather failed (%d) on batch statistics", rc);
+  const int rc = gather(t, reinterpret_cast<const float*>(sums), reinterpret_cast<float*>(t->gbuf), 2 * (int64_t)width, "batch statistics");
+  if (rc) return rc;
   TK(ian_k_tree_sum(t->gbuf, t->world, width, sums, t->st));
   return 0;
 }
@@ -606,6 +665,16 @@ int acc(ian_trainer* t, const std::string& pname, const float* src, int64_t coun
 int acc64(ian_trainer* t, const std::string& pname, const double* src, int64_t count, double alpha = 1.0) {  // from float64 column sums
   TK(ian_k_axpy_f64(alpha, src, G(t, pname), count, t->touched.count(pname) ? 1 : 0, t->st));
   return mark(t, {pname});
+}
+// exact mode, after the per-rank sums have been combined over the ranks: affine, apply, running averages (same running_math as the
+// fused single-process second stage: data-parallel checkpoints carry bit-identical running averages)
+int bn_forward_finish(ian_trainer* t, BN& bn, const float* y, float* a, int64_t rows, int C, int stride, const float* gamma, const float* beta,
+                      int act, int64_t count_rows, float* rm, float* ri) {
+  bn.count = (float)(count_rows * t->world);
+  TK(ian_k_bn_make_affine(bn.sums, bn.count, BN_EPS, gamma, beta, C, bn.mean, bn.inv_std, bn.scale, bn.shift, t->st));
+  TK(ian_k_affine(y, a, bn.scale, bn.shift, rows, C, stride, act, t->st));
+  if (rm) TK(ian_k_bn_running(rm, bn.mean, ri, bn.inv_std, C, 0.9f, 0.1f, t->st));
+  return 0;
 }
 int bn_forward(ian_trainer* t, BN& bn, const float* y, float* a, int64_t rows, int C, int stride, const float* gamma, const float* beta, int act,
                int64_t count_rows, const char* running) {
@@ -626,15 +695,10 @@ int bn_forward(ian_trainer* t, BN& bn, const float* y, float* a, int64_t rows, i
   }
   TK(ian_k_colstats(0, y, nullptr, nullptr, nullptr, nullptr, rows, C, stride, 0, ws, chunks(t, rows), bn.sums, t->st));
   if ((rc = allreduce_ordered(t, bn.sums, 2 * C))) return rc;
-  bn.count = (float)(count_rows * t->world);
-  TK(ian_k_bn_make_affine(bn.sums, bn.count, BN_EPS, gamma, beta, C, bn.mean, bn.inv_std, bn.scale, bn.shift, t->st));
-  TK(ian_k_affine(y, a, bn.scale, bn.shift, rows, C, stride, act, t->st));
-  if (rm) {
-    TK(ian_k_axpy(0.9f, rm, rm, C, 0, t->st)); TK(ian_k_axpy(0.1f, bn.mean, rm, C, 1, t->st));
-    TK(ian_k_axpy(0.9f, ri, ri, C, 0, t->st)); TK(ian_k_axpy(0.1f, bn.inv_std, ri, C, 1, t->st));
-  }
-  return 0;
+  return bn_forward_finish(t, bn, y, a, rows, C, stride, gamma, beta, act, count_rows, rm, ri);
 }
+int bn_backward_finish(ian_trainer* t, BN& bn, const float* dA, const float* a, const float* y, float* dy, int64_t rows, int C, int stride, int act,
+                       const std::string& gname, const std::string& bname, bool want_w);
 int bn_backward(ian_trainer* t, BN& bn, const float* dA, const float* a, const float* y, float* dy, int64_t rows, int C, int stride, int act,
                 const std::string& gname, const std::string& bname, bool want_w) {
   double* ws;
@@ -654,6 +718,11 @@ int bn_backward(ian_trainer* t, BN& bn, const float* dA, const float* a, const f
   }
   TK(ian_k_colstats(1, dA, a, y, bn.mean, bn.inv_std, rows, C, stride, act, ws, chunks(t, rows), bn.bsums, t->st));
   if ((rc = allreduce_ordered(t, bn.bsums, 2 * C))) return rc;
+  return bn_backward_finish(t, bn, dA, a, y, dy, rows, C, stride, act, gname, bname, want_w);
+}
+int bn_backward_finish(ian_trainer* t, BN& bn, const float* dA, const float* a, const float* y, float* dy, int64_t rows, int C, int stride, int act,
+                       const std::string& gname, const std::string& bname, bool want_w) {
+  int rc;
   if (want_w) {
     // with exact statistics every rank already holds the GLOBAL dbeta / dgamma: pre-divide so that the gradient all-reduce
     // (a sum over ranks) restores them
@@ -744,8 +813,7 @@ int enc_forward(ian_trainer* t, Bufs& E, std::map<std::string, BN>& bn, const fl
   const float* act_all = E["act"];
   int nall = n, row0 = 0;
   if (t->exact) {  // the kernel features couple every sample with every other one of the GLOBAL minibatch (layers.py:506-520)
-    rc = t->comm.allgather(t->comm.ctx, E["act"], E["act_all"], (int64_t)n * cs(2500), t->st);
-    if (rc) return tfail(t, -30, "comm.allgather failed (%d) on the MinibatchLayer activations", rc);
+    if ((rc = gather(t, E["act"], E["act_all"], (int64_t)n * cs(2500), "the MinibatchLayer activations"))) return rc;
     act_all = E["act_all"]; nall = t->N; row0 = t->rank * n;
   }
   TK(ian_k_mb_forward(act_all, nall, cs(2500), row0, n, 500, 5, P(t, "minibatch_discrim.b"), E["feat"], 1024, 1024, E["mb"], cs(1524), t->st));
@@ -770,8 +838,7 @@ int enc_backward(ian_trainer* t, Bufs& E, std::map<std::string, BN>& bn, int t0,
     const float *act_all = E["act"], *dmb_all = E["dmb"];
     int nall = n, row0 = 0;
     if (t->exact) {  // a sample's activations feed every other sample's kernel features: their gradients come from all ranks
-      rc = t->comm.allgather(t->comm.ctx, E["dmb"], E["dmb_all"], (int64_t)n * cs(1524), t->st);
-      if (rc) return tfail(t, -30, "comm.allgather failed (%d) on the MinibatchLayer gradients", rc);
+      if ((rc = gather(t, E["dmb"], E["dmb_all"], (int64_t)n * cs(1524), "the MinibatchLayer gradients"))) return rc;
       act_all = E["act_all"]; dmb_all = E["dmb_all"]; nall = t->N; row0 = t->rank * n;
     }
     TK(ian_k_mb_backward(act_all, nall, cs(2500), row0, n, 500, 5, dmb_all + 1024, cs(1524), E["dact"], cs(2500), t->st));
@@ -816,10 +883,27 @@ int z_forward(ian_trainer* t, const float* a4, const float* eps) {
                        "bnorm_enc_fc1")))
     return rc;
   const char* trip[2][3] = {{"mu", "enc_mu", "mu_bnorm"}, {"ls", "enc_logsigma", "ls_bnorm"}};
-  for (auto& tr : trip) {
-    const std::string nm = tr[0], bnn = tr[2];
-    TL(lay(t, tr[1]), ian_layer_forward(lay(t, tr[1]), S["f"], n, S["y_" + nm], 128, nullptr, nullptr, 0, t->st));
-    if ((rc = bn_forward(t, t->bnZ["bn_" + nm], S["y_" + nm], S[nm], n, Z, 128, P(t, bnn + ".gamma"), P(t, bnn + ".beta"), 0, n, tr[2]))) return rc;
+  if (!t->exact) {
+    for (auto& tr : trip) {
+      const std::string nm = tr[0], bnn = tr[2];
+      TL(lay(t, tr[1]), ian_layer_forward(lay(t, tr[1]), S["f"], n, S["y_" + nm], 128, nullptr, nullptr, 0, t->st));
+      if ((rc = bn_forward(t, t->bnZ["bn_" + nm], S["y_" + nm], S[nm], n, Z, 128, P(t, bnn + ".gamma"), P(t, bnn + ".beta"), 0, n, tr[2]))) return rc;
+    }
+  } else {  // both layers, both per-rank statistics, ONE all-gather of the adjacent sums, then both normalisations
+    double* ws;
+    if ((rc = ws_for(t, n, Z, &ws))) return rc;
+    for (auto& tr : trip) {
+      const std::string nm = tr[0];
+      TL(lay(t, tr[1]), ian_layer_forward(lay(t, tr[1]), S["f"], n, S["y_" + nm], 128, nullptr, nullptr, 0, t->st));
+      TK(ian_k_colstats(0, S["y_" + nm], nullptr, nullptr, nullptr, nullptr, n, Z, 128, 0, ws, chunks(t, n), t->bnZ["bn_" + nm].sums, t->st));
+    }
+    if ((rc = allreduce_ordered(t, t->bnZ["bn_mu"].sums, 4 * Z))) return rc;
+    for (auto& tr : trip) {
+      const std::string nm = tr[0], bnn = tr[2];
+      float *rm = nullptr, *ri = nullptr;
+      if (t->update_running) { rm = P(t, bnn + ".mean"); ri = P(t, bnn + ".inv_std"); }
+      if ((rc = bn_forward_finish(t, t->bnZ["bn_" + nm], S["y_" + nm], S[nm], n, Z, 128, P(t, bnn + ".gamma"), P(t, bnn + ".beta"), 0, n, rm, ri))) return rc;
+    }
   }
   TK(ian_k_sample(S["mu"], S["ls"], eps, S["z0"], S["kl"], n, Z, 128, Z, t->st));
   TK(ian_k_made_iaf(S["z0"], S["z"], t->made_w, t->made_b, n, Z, 128, t->st));
@@ -835,10 +919,22 @@ int z_backward(ian_trainer* t, const float* dz, const float* a4) {
   TK(ian_k_sample_bwd(S["mu"], S["ls"], t->eps, S["dz0"], S["dmu"], S["dls"], n, Z, 128, Z, klw, t->st));
   const char* trip[2][3] = {{"mu", "enc_mu", "mu_bnorm"}, {"ls", "enc_logsigma", "ls_bnorm"}};
   bool first = true;
+  if (t->exact) {  // both gradient statistics, ONE all-gather (the sums are adjacent: z_alloc)
+    double* ws;
+    if ((rc = ws_for(t, n, Z, &ws))) return rc;
+    for (auto& tr : trip) {
+      const std::string nm = tr[0];
+      BN& b = t->bnZ["bn_" + nm];
+      TK(ian_k_colstats(1, S["d" + nm], nullptr, S["y_" + nm], b.mean, b.inv_std, n, Z, 128, 0, ws, chunks(t, n), b.bsums, t->st));
+    }
+    if ((rc = allreduce_ordered(t, t->bnZ["bn_mu"].bsums, 4 * Z))) return rc;
+  }
   for (auto& tr : trip) {
     const std::string nm = tr[0], bnn = tr[2];
     float* d = S["d" + nm];
-    if ((rc = bn_backward(t, t->bnZ["bn_" + nm], d, nullptr, S["y_" + nm], d, n, Z, 128, 0, bnn + ".gamma", bnn + ".beta", true))) return rc;
+    if (t->exact) rc = bn_backward_finish(t, t->bnZ["bn_" + nm], d, nullptr, S["y_" + nm], d, n, Z, 128, 0, bnn + ".gamma", bnn + ".beta", true);
+    else rc = bn_backward(t, t->bnZ["bn_" + nm], d, nullptr, S["y_" + nm], d, n, Z, 128, 0, bnn + ".gamma", bnn + ".beta", true);
+    if (rc) return rc;
     if ((rc = wgrad(t, tr[1], S["f"], d))) return rc;
     TL(lay(t, tr[1]), ian_layer_backward_data(lay(t, tr[1]), d, n, S["df"], 1024, first ? 0 : 1, t->st));
     first = false;
@@ -960,6 +1056,10 @@ int dec_backward(ian_trainer* t, Bufs& D, std::map<std::string, BN>& bn, const f
 int forward(ian_trainer* t, const float* X, const float* Zr, const float* eps) {  // the three passes of train_IAN.py:116-149
   const int n = t->n, Z = t->cfg.num_latents;
   int rc;
+  if (t->measure_exposed && t->world > 1) {   // this step's all-gather events go to the pool of two steps ago: fold it first
+    t->gpar ^= 1;
+    fold_gathers(t, t->gpar);
+  }
   if ((rc = refresh_weights(t))) return rc;
   t->X = X;
   t->eps = eps;
@@ -973,7 +1073,9 @@ int forward(ian_trainer* t, const float* X, const float* Zr, const float* eps) {
   return enc_forward(t, t->EG, t->bnEG, t->xgen_override ? t->xgen_override : t->DG["xhat"], 0, 2, 2, false);  // p_X_gen
 }
 
-int metrics(ian_trainer* t, float* out9) {  // all scalar losses of train_IAN.py:169-250,279 (one device->host copy)
+// all scalar losses of train_IAN.py:169-250,279: partial sums on the device (+ their all-reduce: issued on EVERY data-parallel step,
+// with or without a reader, so that ranks that disagree on `metrics` keep identical collective sequences), then one device->host copy
+int metrics_device(ian_trainer* t) {
   const int n = t->n;
   const float N = (float)t->N;   // means are over the GLOBAL batch
   float* s = t->scalars;
@@ -993,6 +1095,10 @@ int metrics(ian_trainer* t, float* out9) {  // all scalar losses of train_IAN.py
     if (!rc) rc = t->comm.wait_all(t->comm.ctx, t->st);
     if (rc) return tfail(t, -30, "comm all-reduce of the metrics failed (%d)", rc);
   }
+  return 0;
+}
+int metrics_read(ian_trainer* t, float* out9) {
+  float* s = t->scalars;
   float v[32];
   THIP(hipMemcpyAsync(v, s, sizeof v, hipMemcpyDeviceToHost, t->st));
   THIP(hipStreamSynchronize(t->st));
@@ -1006,6 +1112,10 @@ int metrics(ian_trainer* t, float* out9) {  // all scalar losses of train_IAN.py
   out9[7] = 1.f - v[17];                      // pixel_acc
   out9[8] = v[20] + v[22] + v[24] + v[26];    // feature_loss
   return 0;
+}
+int metrics(ian_trainer* t, float* out9) {
+  const int rc = metrics_device(t);
+  return rc ? rc : metrics_read(t, out9);
 }
 
 int backward(ian_trainer* t, bool gen) {  // gradients of the update rules of train_IAN.py:253-273 (Z_params always)
@@ -1233,7 +1343,8 @@ int check_step_args(ian_trainer* t, const float* x, const float* zrand, const fl
 int step_body(ian_trainer* t, bool gen, const float* x, const float* zrand, const float* eps, float* metrics9) {
   int rc;
   if ((rc = forward(t, x, zrand, eps))) return rc;
-  if (metrics9 && (rc = metrics(t, metrics9))) return rc;
+  if ((metrics9 || t->world > 1) && (rc = metrics_device(t))) return rc;
+  if (metrics9 && (rc = metrics_read(t, metrics9))) return rc;
   if ((rc = backward(t, gen))) return rc;
   if ((rc = finish_allreduce(t, gen ? 0 : 1))) return rc;
   if ((rc = regularizers(t, gen))) return rc;
@@ -1424,6 +1535,13 @@ int ian_trainer_stat(ian_trainer* t, const char* key, double* out) {
     }
     const int w = k == "exposed_ms_gen" ? 0 : 1;
     *out = t->exposed_n[w] ? t->exposed_ms[w] / t->exposed_n[w] : 0.0;
+  } else if (k == "gather_ms_gen" || k == "gather_ms_discrim" || k == "gathers_gen" || k == "gathers_discrim") {
+    THIP(hipDeviceSynchronize());
+    fold_gathers(t, 0);
+    fold_gathers(t, 1);
+    const int w = (k == "gather_ms_gen" || k == "gathers_gen") ? 0 : 1;
+    const double d = t->gather_n[w] ? (double)t->gather_n[w] : 1.0;
+    *out = (k.compare(0, 10, "gather_ms_") == 0 ? t->gather_ms[w] : t->gather_calls[w]) / d;
   } else if (k == "plan_buckets_gen") *out = t->plans.count(0) ? (double)t->plans[0].size() : 0.0;
   else if (k == "plan_buckets_discrim") *out = t->plans.count(1) ? (double)t->plans[1].size() : 0.0;
   else if (k == "overlap_log") *out = (double)t->overlap_log.size();
@@ -1501,7 +1619,11 @@ int ian_trainer_set_option(ian_trainer* t, const char* key, double value) {
   else if (k == "update_running") t->update_running = value != 0.0;
   else if (k == "overlap") t->overlap = value != 0.0;                       // gradient buckets handed over during backward
   else if (k == "bucket_bytes") { t->bucket_bytes = (int64_t)value > 4 ? (int64_t)value : 4; t->plans.clear(); }
-  else if (k == "measure_exposed") { t->measure_exposed = value != 0.0; t->exposed_ms[0] = t->exposed_ms[1] = 0; t->exposed_n[0] = t->exposed_n[1] = 0; t->ex_pending = false; }
+  else if (k == "measure_exposed") {
+    (void)hipDeviceSynchronize();
+    t->measure_exposed = value != 0.0; t->exposed_ms[0] = t->exposed_ms[1] = 0; t->exposed_n[0] = t->exposed_n[1] = 0; t->ex_pending = false;
+    for (int w = 0; w < 2; ++w) { t->gev_used[w] = 0; t->gather_ms[w] = t->gather_calls[w] = 0; t->gather_n[w] = 0; }
+  }
   else return tfail(t, -1, "unknown option '%s'", key);
   return 0;
 }
@@ -1522,6 +1644,8 @@ void ian_trainer_destroy(ian_trainer* t) {
   if (t->st_comm) (void)hipStreamDestroy(t->st_comm);
   if (t->ex0) (void)hipEventDestroy(t->ex0);
   if (t->ex1) (void)hipEventDestroy(t->ex1);
+  for (auto& pool : t->gev)
+    for (auto& e : pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& kv : t->layers) ian_layer_destroy(kv.second.l);
   for (float* p : t->allocs)
     if (p) (void)hipFree(p);

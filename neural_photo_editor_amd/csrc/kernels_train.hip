@@ -369,6 +369,23 @@ hipError_t launch_bn_make_affine(const double* sums, float count, float eps, con
   return hipGetLastError();
 }
 
+// running averages of one normalisation, in place: r <- keep * r + alpha * batch for mean and inv_std in ONE launch, with the
+// same running_math the fused single-process second stage (bn_finish_kernel) uses -- the data-parallel `exact` step (whose
+// statistics pass through an all-gather between the tree and bn_make_affine) updates them bit for bit like the 1-GPU step.
+// (Round 4 did this with four axpy launches whose x and y aliased under __restrict__.)
+__global__ __launch_bounds__(256) void bn_running_kernel(float* run_mean, const float* __restrict__ mean, float* run_inv_std,
+                                                         const float* __restrict__ inv_std, int C, float keep, float alpha) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  run_mean[c] = running_math(run_mean[c], mean[c], keep, alpha);
+  run_inv_std[c] = running_math(run_inv_std[c], inv_std[c], keep, alpha);
+}
+hipError_t launch_bn_running(float* run_mean, const float* mean, float* run_inv_std, const float* inv_std, int C, float keep,
+                             float alpha, hipStream_t s) {
+  hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, s, run_mean, mean, run_inv_std, inv_std, C, keep, alpha);
+  return hipGetLastError();
+}
+
 // backward through [batch-norm ->] activation:   g = dA * act'(a)
 //   bn:   dy = scale * (g - s1/N - xhat * s2/N),  xhat = (y - mean) * inv_std,  (s1, s2) = sums from colstats mode 1
 //   else: dy = g
@@ -409,8 +426,8 @@ hipError_t launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s) {
 }
 
 // y (+)= alpha * x on flat buffers (gradient accumulation, L2 regulariser gradient 2*reg*p)
-__global__ __launch_bounds__(256) void axpy_kernel(float alpha, const float* __restrict__ x, float* __restrict__ y,
-                                                   long long n, int accumulate) {
+// (no __restrict__: callers may pass x == y, e.g. an in-place scale)
+__global__ __launch_bounds__(256) void axpy_kernel(float alpha, const float* x, float* y, long long n, int accumulate) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
     y[i] = (accumulate ? y[i] : 0.f) + alpha * x[i];
 }

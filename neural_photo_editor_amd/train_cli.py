@@ -53,7 +53,7 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     from . import checkpoints, config_loader, lowering, train_loop
-    from .trainer import Comm, Trainer
+    from .trainer import Trainer, default_comm
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -77,7 +77,10 @@ def main(argv=None):
         raise SystemExit("cfg['batch_size']=%d is not divisible by the %d ranks; pass --batch" % (cfg["batch_size"], world))
     batch = args.batch or cfg["batch_size"] // world
     cfg["batch_size"] = batch * world
-    trainer = Trainer(args.config_path, params, batch=batch, comm=Comm(), exact=not args.local_statistics)
+    comm = default_comm()     # N > 1: the torch-free librccl filler (falls back to torch.distributed on all ranks together)
+    trainer = Trainer(args.config_path, params, batch=batch, comm=comm, exact=not args.local_statistics)
+    if world > 1:
+        logging.info("data parallel: %d ranks, collectives through %s", world, comm.filler)
     images = load_images(args.data)
     rank = int(os.environ.get("RANK", "0"))
 

@@ -48,10 +48,18 @@ def mdcl_names(name, scales):
 # communication (RCCL through torch.distributed; gloo in the CPU tests)
 # ======================================================================================================
 class Comm:
-    """Sum-all-reduce / all-gather for the data-parallel step.  ``bucket_bytes`` sizes the gradient buckets for
-    xGMI (point-to-point links: a few large messages)."""
+    """The collective table of the C trainer (include/ian_train.h: ian_comm_ops) filled from ``torch.distributed`` -- backend
+    "nccl" is RCCL over xGMI; gloo in the tests.  ``bucket_bytes`` sizes the gradient buckets the C sequencer cuts for xGMI
+    (point-to-point links: a few large messages).
 
-    def __init__(self, group=None, bucket_bytes=16 << 20):
+    The batch-statistics / MinibatchLayer all-gathers of ``exact`` mode get their OWN process group (``gather_group``):
+    torch's NCCL backend runs every collective of one group on one internal stream in issue order, so on a shared group a
+    16 MB gradient bucket handed over during backward would sit in front of the next small all-gather the compute stream
+    blocks on.  ``filler`` names what ended up carrying the collectives (bench.py prints it)."""
+
+    filler = "torch.distributed"
+
+    def __init__(self, group=None, bucket_bytes=16 << 20, gather_group="own"):
         import torch.distributed as dist
         self.dist = dist
         self.active = dist.is_available() and dist.is_initialized()
@@ -59,102 +67,136 @@ class Comm:
         self.world = dist.get_world_size(group) if self.active else 1
         self.rank = dist.get_rank(group) if self.active else 0
         self.bucket_bytes = bucket_bytes
+        if gather_group == "own":              # collective call: every rank constructs its Comm
+            gather_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None) \
+                if self.active and self.world > 1 else group
+        self.gather_group = gather_group
+        self.errors = []
 
-    def all_reduce_sum(self, t, async_op=False):
-        if self.world == 1:
-            return None
-        return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
-
-    def all_reduce_buckets(self, flat, async_op=False):
-        """flat: 1-D tensor; reduces it in bucket_bytes pieces; returns the work handles (async) or []."""
-        if self.world == 1:
-            return []
-        n = flat.numel()
-        step = max(1, self.bucket_bytes // flat.element_size())
-        works = []
-        for o in range(0, n, step):
-            w = self.dist.all_reduce(flat[o:min(n, o + step)], op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
-            if async_op:
-                works.append(w)
-        return works
-
-    def barrier(self):
-        if self.world > 1:
-            self.dist.barrier(group=self.group)
-
-    # ---- the collective callback table of the C trainer (include/ian_train.h: ian_comm_ops) ----------------------------
-    def _stream(self, torch, ptr):
-        return torch.cuda.default_stream() if not ptr else torch.cuda.ExternalStream(int(ptr))
-
-    def ops(self, torch):
-        """ian_comm_ops filled from torch.distributed: the trainer calls these with raw device pointers and HIP streams.
+    # ---- the collective callback table of the C trainer ----------------------------------------------------------------
+    def ops(self, torch, host=False):
+        """ian_comm_ops filled from torch.distributed: the trainer calls these with raw device pointers and HIP streams
+        (host=True: raw HOST pointers, streams ignored -- what the CPU gloo tests drive the table with).
         allreduce_sum: async all-reduce issued with the trainer's side stream current (RCCL orders it behind that stream and
         runs it on its own; gloo copies through the host) -- wait_all makes the compute stream wait for the works."""
+        import contextlib
         self._works, self._views = [], {}
 
         def view(ptr, count):
             key = (int(ptr), int(count))
             t = self._views.get(key)
             if t is None:
-                t = self._views[key] = device_view(torch, ptr, (int(count),))
+                t = self._views[key] = host_view(torch, ptr, int(count)) if host else device_view(torch, ptr, (int(count),))
             return t
 
+        def on(stream):
+            if host:
+                return contextlib.nullcontext()
+            return torch.cuda.stream(torch.cuda.default_stream() if not stream else torch.cuda.ExternalStream(int(stream)))
+
         def allreduce(buf, count, stream):
-            with torch.cuda.stream(self._stream(torch, stream)):
+            with on(stream):
                 self._works.append(self.dist.all_reduce(view(buf, count), op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 
         def wait_all(stream):
-            with torch.cuda.stream(self._stream(torch, stream)):
+            with on(stream):
                 for w in self._works:
                     w.wait()                      # RCCL: the given stream waits (device side); gloo: host wait
             self._works = []
 
         def allgather(src, dst, count, stream):
-            with torch.cuda.stream(self._stream(torch, stream)):
+            with on(stream):
                 self.all_gather_rows(view(src, count).view(1, -1), view(dst, count * self.world).view(self.world, -1))
 
         self.errors = []
         return build_ops(self.world, self.rank, allreduce, wait_all, allgather, self.errors)
 
     def all_gather_rows(self, local, out):
-        """out[(rank*n):(rank+1)*n] = local over all ranks (row blocks of equal size)."""
+        """out[(rank*n):(rank+1)*n] = local over all ranks (row blocks of equal size), on the gather group."""
         if self.world == 1:
             out.copy_(local)
             return
-        if self.dist.get_backend(self.group) == "nccl":       # RCCL: one fused all-gather
-            self.dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
-        else:                                                   # gloo (tests): list form, row blocks are views of `out`
-            self.dist.all_gather(list(out.chunk(self.world, dim=0)), local.contiguous(), group=self.group)
+        if self.dist.get_backend(self.gather_group) == "nccl":       # RCCL: one fused all-gather
+            self.dist.all_gather_into_tensor(out, local.contiguous(), group=self.gather_group)
+        else:                                                          # gloo (tests): list form, row blocks are views of `out`
+            self.dist.all_gather(list(out.chunk(self.world, dim=0)), local.contiguous(), group=self.gather_group)
+
+    def close(self):
+        pass
 
 
 class NativeRcclComm(Comm):
     """The same data-parallel step with the collective table filled by libian itself from librccl (csrc/ian_comm_rccl.cpp:
-    ncclAllReduce / ncclAllGather on the trainer's streams) -- the route a C caller takes; torch.distributed is used ONCE, to hand
-    rank 0's 128-byte communicator id to the other ranks.  One GPU per rank (RCCL refuses two ranks on one device), so the
-    shared-GPU gloo tests cannot drive it: covered at world size 1 (tests/test_gpu_dp.py) and by construction."""
+    ncclAllReduce on one communicator, ncclAllGather on a second one, on the trainer's streams) -- the route a C caller takes,
+    and the default of bench.py / train_cli.py at N > 1.  torch.distributed is used ONLY to hand rank 0's two 128-byte
+    communicator ids to the other ranks and to agree on the outcome: if any rank cannot set the communicators up (no librccl,
+    two ranks on one device, ...) EVERY rank falls back to the torch.distributed filler of the base class, and ``filler`` says so.
+    One GPU per rank (RCCL refuses two ranks on one device), so the shared-GPU gloo tests cannot drive the native table with two
+    ranks: covered at world size 1 (tests/test_gpu_dp.py), by the fallback agreement test, and by construction."""
 
-    def ops(self, torch):
+    filler = "librccl (native, 2 communicators)"
+
+    def __init__(self, group=None, bucket_bytes=16 << 20):
+        Comm.__init__(self, group, bucket_bytes, gather_group=None)   # a gather GROUP is created only if the fallback needs it
+        self._native_ops = None
+
+    def ops(self, torch, host=False):
         lib = load_train_library()
-        ident = C.create_string_buffer(128)
+        err = lambda: (lib.ian_rccl_last_error() or b"?").decode()
+        ids, why = None, ""
         if self.rank == 0:
-            rc = lib.ian_rccl_unique_id(ident)
-            if rc:
-                raise IanTrainError("ian_rccl_unique_id failed (%d): %s" % (rc, (lib.ian_rccl_last_error() or b"?").decode()))
+            bufs = [C.create_string_buffer(128), C.create_string_buffer(128)]
+            rcs = [lib.ian_rccl_unique_id(b) for b in bufs]
+            if any(rcs):
+                why = "ian_rccl_unique_id failed (%s): %s" % (rcs, err())
+            else:
+                ids = [b.raw for b in bufs]
         if self.world > 1:
-            box = [ident.raw]
+            box = [ids]
             self.dist.broadcast_object_list(box, src=0, group=self.group)
-            ident = C.create_string_buffer(box[0], 128)
-        o = CommOps()
-        rc = lib.ian_rccl_comm_create(ident, self.rank, self.world, C.byref(o))
-        if rc:
-            raise IanTrainError("ian_rccl_comm_create failed (%d): %s" % (rc, (lib.ian_rccl_last_error() or b"?").decode()))
-        self.errors, self._lib, self._native_ops = [], lib, o
-        return o
+            ids = box[0]
+        o, ok = CommOps(), False
+        if ids is not None and not host:
+            rc = lib.ian_rccl_comm_create(C.create_string_buffer(ids[0], 128), self.rank, self.world, C.byref(o))
+            if rc:
+                why = "ian_rccl_comm_create failed (%d): %s" % (rc, err())
+            else:
+                self._lib, self._native_ops = lib, o
+                rc = lib.ian_rccl_comm_add_gather(C.byref(o), C.create_string_buffer(ids[1], 128))
+                if rc:
+                    why = "ian_rccl_comm_add_gather failed (%d): %s" % (rc, err())
+                ok = rc == 0
+        elif host:
+            why = "host buffers requested"
+        if self.world > 1:                         # all ranks take the same route
+            oks = [None] * self.world
+            self.dist.all_gather_object(oks, (bool(ok), why), group=self.group)
+            bad = [w for k, w in oks if not k]
+            if bad:
+                ok, why = False, next((w for w in bad if w), "another rank failed")
+        if ok:
+            self.errors = []
+            return o
+        self.close()
+        if self.world == 1:
+            raise IanTrainError(why or "librccl communicator could not be created")
+        self.filler = "torch.distributed (fallback: %s)" % why
+        self.gather_group = self.dist.new_group(ranks=self.dist.get_process_group_ranks(self.group) if self.group is not None else None)
+        return Comm.ops(self, torch, host=host)
 
     def close(self):
         if getattr(self, "_native_ops", None) is not None:
             self._lib.ian_rccl_comm_destroy(C.byref(self._native_ops))
             self._native_ops = None
+
+
+def default_comm(bucket_bytes=16 << 20):
+    """The communicator bench.py / train_cli.py use: the torch-free RCCL filler when torch.distributed runs on RCCL ("nccl"), the
+    torch.distributed filler otherwise (gloo: CPU rehearsals, ranks sharing one GPU) or when no process group exists."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == "nccl":
+        return NativeRcclComm(bucket_bytes=bucket_bytes)
+    return Comm(bucket_bytes=bucket_bytes)
 
 
 # ======================================================================================================
@@ -369,6 +411,14 @@ def device_view(torch, ptr, shape, dtype="f4"):
     return t.view(*shape)
 
 
+def host_view(torch, ptr, n, dtype=np.float32):
+    """torch tensor over n elements of HOST memory at ``ptr`` (no copy; the memory must outlive the view)."""
+    if not ptr or n <= 0:
+        raise IanTrainError("host_view: null pointer or empty shape")
+    ct = {np.float32: C.c_float, np.float64: C.c_double}[dtype]
+    return torch.from_numpy(np.ctypeslib.as_array(C.cast(C.c_void_p(int(ptr)), C.POINTER(ct)), shape=(int(n),)))
+
+
 class CommOps(C.Structure):
     """ian_comm_ops (include/ian_train.h)"""
     AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
@@ -512,6 +562,7 @@ class Trainer:
         rc = self.lib.ian_trainer_create(C.byref(tc), C.byref(self._h))
         if rc:
             raise IanTrainError("ian_trainer_create failed (%d)%s" % (rc, ": no HIP device, libian has no CPU fallback" if rc == -10 else ""))
+        self._ops = None
         if self.comm.world > 1:
             self._ops = self.comm.ops(torch)                      # keeps the callbacks alive as long as the trainer
             self._check(self.lib.ian_trainer_set_comm(self._h, C.byref(self._ops), int(self.exact)))
@@ -686,8 +737,14 @@ class Trainer:
         return int(self.stat("plan_buckets_" + which))
 
     def allreduce_exposed_ms(self):
-        """Mean stall of the compute stream on the gradient all-reduce per update kind (set measure_exposed = True first)."""
+        """Mean stall of the compute stream at wait_all per update kind -- the part of the gradient all-reduce backward did not
+        hide, the wait_all stall ONLY (set measure_exposed = True first); ``allgather_ms`` is the other half of the picture."""
         return {w: self.stat("exposed_ms_" + w) for w in ("gen", "discrim")}
+
+    def allgather_ms(self):
+        """Mean time per update the compute stream spends inside the exact-mode all-gathers (batch statistics, MinibatchLayer),
+        and their number per update (measure_exposed = True)."""
+        return {w: {"ms": self.stat("gather_ms_" + w), "calls": self.stat("gathers_" + w)} for w in ("gen", "discrim")}
 
     # ---- parameters / checkpoints (GANcheckpoints.py format, Theano parameter names: train_IAN.py:563-569) -------
     def read(self, name, grad=False):
@@ -721,6 +778,9 @@ class Trainer:
         if getattr(self, "_h", None) and self._h.value:
             self.lib.ian_trainer_destroy(self._h)
             self._h = C.c_void_p()
+            if getattr(self, "_ops", None) is not None:      # the communicators die after the trainer that used their table
+                self.comm.close()
+                self._ops = None
 
     def __del__(self):
         try:

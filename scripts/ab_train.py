@@ -4,11 +4,11 @@ import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from neural_photo_editor_amd import synthetic as O
-from neural_photo_editor_amd.ctrainer import CTrainer
+from neural_photo_editor_amd.trainer import Trainer
 key, vals = sys.argv[1].split("=")
 va, vb = [float(v) for v in vals.split(",")]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-tr = CTrainer(os.path.join(ROOT, "neural_photo_editor_amd", "configs", "IAN.py"), O.make_train_params(O.make_params("IAN", 1)), B)
+tr = Trainer(os.path.join(ROOT, "neural_photo_editor_amd", "configs", "IAN.py"), O.make_train_params(O.make_params("IAN", 1)), B)
 rs = np.random.RandomState(0)
 X = torch.from_numpy(O.make_images(B, seed=1)).cuda()
 Z = torch.from_numpy(rs.randn(B, 100).astype(np.float32)).cuda()

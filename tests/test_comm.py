@@ -1,5 +1,8 @@
-"""world_size-2 gloo tests (CPU) of the data-parallel host logic of the training step (trainer.Comm) and of the
-replica sharding bench.py uses for the reconstruction metric."""
+"""world_size-2 gloo tests (CPU) of the data-parallel host logic of the training step: the ian_comm_ops callback table
+(trainer.build_ops <- trainer.Comm.ops) driven the way the C sequencer drives it (csrc/ian_trainer.cpp: fire / finish_allreduce /
+allreduce_ordered / gather) -- raw buffer addresses through the C function pointers, here on HOST buffers -- the all-rank
+fallback agreement of NativeRcclComm, and bench.py's own multi-rank launch."""
+import ctypes as C
 import os
 import socket
 
@@ -18,69 +21,118 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _tree(parts):
+    """the pairwise tree of ian_k_tree_sum (kernels_train.hip tree_sum_seq): T(lo,hi) = T(lo,lo+m) + T(lo+m,hi), m = the largest
+    power of two below hi-lo"""
+    if len(parts) == 1:
+        return parts[0]
+    m = 1
+    while m * 2 < len(parts):
+        m *= 2
+    return _tree(parts[:m]) + _tree(parts[m:])
+
+
+def _drive_table(comm, ops, rank, world):
+    """What one data-parallel update asks of the table, with the sequencer's call pattern and host buffers."""
+    rs = np.random.RandomState(0)
+    # (1) gradient buckets: a flat group cut into bucket_bytes pieces, each handed to allreduce_sum as it becomes ready (here: in
+    # reverse order, as backward produces them), then ONE wait_all before the optimiser reads the gradients
+    full = rs.randn(world, 1777).astype(np.float32)
+    g = full[rank].copy()
+    step = comm.bucket_bytes // 4
+    cuts = [(o, min(g.size, o + step)) for o in range(0, g.size, step)]
+    assert len(cuts) >= 7
+    for lo, hi in reversed(cuts):
+        assert ops.allreduce_sum(ops.ctx, g.ctypes.data + 4 * lo, hi - lo, None) == 0
+    assert ops.wait_all(ops.ctx, None) == 0
+    assert ops.wait_all(ops.ctx, None) == 0                      # nothing pending: a no-op, not an error
+    ok1 = np.allclose(g, full.sum(0), rtol=1e-6, atol=1e-6)
+    # (2) SyncBN: float64 [2][C] sums travel as pairs of floats (allreduce_ordered: count = 2 * width), every rank combines the
+    # gathered rows in RANK ORDER with the pairwise tree -> all ranks hold bitwise the same statistics
+    x = rs.randn(world * 8, 16).astype(np.float32)
+    local = x[rank * 8:(rank + 1) * 8].astype(np.float64)
+    sums = np.concatenate([local.sum(0), (local ** 2).sum(0)])
+    gbuf = np.zeros((world, sums.size), np.float64)
+    assert ops.allgather(ops.ctx, sums.ctypes.data, gbuf.ctypes.data, 2 * sums.size, None) == 0
+    comb = _tree([gbuf[r] for r in range(world)])
+    want = _tree([np.concatenate([x[r * 8:(r + 1) * 8].astype(np.float64).sum(0), (x[r * 8:(r + 1) * 8].astype(np.float64) ** 2).sum(0)])
+                  for r in range(world)])
+    ok2 = np.array_equal(comb, want)
+    # (3) MinibatchLayer: rank r owns rows [r*n, (r+1)*n) of the global activation matrix
+    act = x[rank * 8:(rank + 1) * 8].copy()
+    act_all = np.zeros_like(x)
+    assert ops.allgather(ops.ctx, act.ctypes.data, act_all.ctypes.data, act.size, None) == 0
+    ok3 = np.array_equal(act_all, x)
+    # (4) a failing callback must come back as an error CODE (the step then fails with -30), never as an exception across C
+    bad = ops.allreduce_sum(ops.ctx, 0, 16, None)
+    ok4 = bad != 0 and len(comm.errors) == 1
+    return ok1, ok2, ok3, ok4
+
+
+def _worker(rank, world, port, q, native):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from neural_photo_editor_amd.trainer import Comm
-        comm = Comm(bucket_bytes=1000)          # tiny buckets: 250 floats -> many pieces
-        assert comm.world == world and comm.rank == rank
-        # gradient all-reduce: per-rank shard gradients sum to the full-batch gradient, whatever the bucket cut
-        rs = np.random.RandomState(0)
-        full = rs.randn(world, 1777).astype(np.float32)
-        g = torch.from_numpy(full[rank].copy())
-        works = comm.all_reduce_buckets(g, async_op=True)
-        for w in works:
-            w.wait()
-        ok1 = np.allclose(g.numpy(), full.sum(0), rtol=1e-6, atol=1e-6)
-        # SyncBN statistics: sums of (x, x^2) over shards == sums over the whole batch
-        x = rs.randn(world * 8, 16).astype(np.float32)
-        local = torch.from_numpy(x[rank * 8:(rank + 1) * 8])
-        s = torch.stack([local.sum(0), (local ** 2).sum(0)]).reshape(-1)
-        comm.all_reduce_sum(s)
-        ok2 = np.allclose(s.numpy(), np.concatenate([x.sum(0), (x ** 2).sum(0)]), rtol=1e-5, atol=1e-5)
-        # MinibatchLayer all-gather: rank r owns rows [r*n, (r+1)*n)
-        out = torch.zeros(world * 8, 16)
-        comm.all_gather_rows(local, out)
-        ok3 = np.array_equal(out.numpy(), x)
-        q.put((rank, ok1, ok2, ok3))
+        from neural_photo_editor_amd import trainer as T
+        if native:
+            # the N > 1 default of bench.py / train_cli.py: the librccl filler; no GPU here (host buffers), so every rank must agree
+            # to fall back to the torch.distributed filler -- together
+            comm = T.NativeRcclComm(bucket_bytes=1000)
+            ops = comm.ops(torch, host=True)
+            assert comm.filler.startswith("torch.distributed (fallback:"), comm.filler
+            assert comm.gather_group is not None
+        else:
+            comm = T.Comm(bucket_bytes=1000)                       # tiny buckets: 250 floats -> 8 pieces
+            assert comm.gather_group is not None and comm.gather_group is not comm.group     # the all-gathers' own group
+            ops = comm.ops(torch, host=True)
+        assert (ops.world, ops.rank) == (world, rank) == (comm.world, comm.rank)
+        q.put((rank,) + _drive_table(comm, ops, rank, world))
+        comm.close()
     finally:
         dist.destroy_process_group()
 
 
-def test_comm_world2_gloo():
+@pytest.mark.parametrize("native", [False, True])
+def test_comm_table_world2_gloo(native):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, native)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [q.get(timeout=180) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
+        assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1]
-    assert all(r[1] and r[2] and r[3] for r in res), res
+    assert all(all(r[1:]) for r in res), res
 
 
-def test_comm_single_process_is_a_noop():
-    from neural_photo_editor_amd.trainer import Comm
-    c = Comm()
-    assert c.world == 1 and c.rank == 0
-    t = torch.ones(5)
-    assert c.all_reduce_buckets(t) == [] and c.all_reduce_sum(t) is None
+def test_comm_single_process():
+    """No process group: world 1, and the all-gather of the table is a copy."""
+    from neural_photo_editor_amd import trainer as T
+    c = T.Comm()
+    assert c.world == 1 and c.rank == 0 and c.filler == "torch.distributed"
+    t = torch.arange(5, dtype=torch.float32)
     out = torch.zeros(5)
     c.all_gather_rows(t, out)
     assert torch.equal(out, t)
+    assert isinstance(T.default_comm(), T.Comm) and not isinstance(T.default_comm(), T.NativeRcclComm)
 
 
-def test_replica_sharding_of_the_reconstruction_metric():
-    """bench.py: N ranks process disjoint shards; whole-job value = sum of per-rank images / max-over-ranks time."""
-    per_rank, steps = 64, 10
-    times = [0.016, 0.017]
-    value = len(times) * per_rank * steps / max(times)
-    assert value == pytest.approx(2 * 64 * 10 / 0.017)
+def test_ian_comm_ops_layout_matches_the_header():
+    """trainer.CommOps is the ctypes mirror of ian_comm_ops (include/ian_train.h): two int32, a context pointer, three function
+    pointers, in that order."""
+    from neural_photo_editor_amd import trainer as T
+    names = [f[0] for f in T.CommOps._fields_]
+    assert names == ["world", "rank", "ctx", "allreduce_sum", "wait_all", "allgather"]
+    assert C.sizeof(T.CommOps) == 8 + 4 * C.sizeof(C.c_void_p)
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ian_train.h")).read()
+    body = hdr[hdr.index("typedef struct ian_comm_ops {"):hdr.index("} ian_comm_ops;")]
+    order = [body.index(k) for k in ("world, rank", "void* ctx", "(*allreduce_sum)", "(*wait_all)", "(*allgather)")]
+    assert order == sorted(order)
 
 
 def test_bench_gpus_flag_launches_its_own_ranks():

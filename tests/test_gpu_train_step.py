@@ -23,10 +23,9 @@ def test_one_call_step_is_bitwise_the_piecewise_step():
     of tests/test_gpu_train*.py and test_gpu_reference_pinned.py drive the pieces, the product calls the one entry -- they must
     be the same arithmetic bit for bit (metrics, every gradient, every parameter and running average after four updates)."""
     import torch
-    from neural_photo_editor_amd.ctrainer import CTrainer, METRICS
-    from neural_photo_editor_amd.trainer import Trainer
+    from neural_photo_editor_amd.trainer import METRICS, Trainer
     P = S.make_train_params(S.make_params("IAN", 1))
-    ct, tr = CTrainer(CFG, P, B), Trainer(CFG, P, batch=B)
+    ct, tr = Trainer(CFG, P, B), Trainer(CFG, P, batch=B)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     for it, which in enumerate(("gen", "discrim", "gen", "discrim")):
         X, Z = S.make_images(B, seed=60 + it), S.make_latents(B, seed=70 + it)
@@ -67,10 +66,10 @@ def test_step_rejects_mistyped_buffers():
 
 def test_c_step_metrics_vs_reference_train_IAN_and_device_pointers():
     import torch
-    from neural_photo_editor_amd.ctrainer import CTrainer, GEN_KEYS
+    from neural_photo_editor_amd.trainer import GEN_KEYS, Trainer
     fx = np.load(os.path.join(GOLD, "ref_train_IAN.npz"))
     P = S.make_train_params(S.make_params("IAN", 1))
-    ct = CTrainer(CFG, P, int(fx["batch"]))
+    ct = Trainer(CFG, P, int(fx["batch"]))
     b = int(fx["batch"])
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     got = ct.update_gen(dev(fx["X"][:b]), dev(fx["Z"][:b]), dev(fx["gen/eps"]))                # device pointers
@@ -84,11 +83,11 @@ def test_c_step_from_host_buffers_only():
     """No torch on the device anywhere: numpy in, nine floats out, parameters read back -- what a C caller does.  (Also the
     scenario tests/test_sanitize.py runs against the ASan/UBSan build: torch's own HIP initialisation does not survive an ASan
     preload on this image, libian's does.)"""
-    from neural_photo_editor_amd.ctrainer import CTrainer, GEN_KEYS, DISCRIM_KEYS
+    from neural_photo_editor_amd.trainer import DISCRIM_KEYS, GEN_KEYS, Trainer
     fx = np.load(os.path.join(GOLD, "ref_train_IAN.npz"))
     b = int(fx["batch"])
     P = S.make_train_params(S.make_params("IAN", 1))
-    ct = CTrainer(CFG, P, b)
+    ct = Trainer(CFG, P, b)
     got = ct.update_gen(fx["X"][:b], fx["Z"][:b], fx["gen/eps"])
     assert np.allclose(got, fx["gen/metrics"], rtol=2e-4, atol=2e-4), (got, fx["gen/metrics"])
     got = np.array(ct.update_discrim(fx["X"][b:], fx["Z"][b:], fx["discrim/eps"]))
@@ -105,13 +104,13 @@ def test_weight_gradient_stream_is_bitwise_the_single_stream_step(which, B):
     """overlap_wgrad=1 (default) issues every weight-gradient GEMM on a second stream, joined before the regularizers.  The
     COLD first step is the sharp case: each layer builds its split-K schedule and zeroes its partial buffer on first use, and that
     zeroing must have landed before the second stream's GEMM writes the same buffer."""
-    from neural_photo_editor_amd.ctrainer import CTrainer
+    from neural_photo_editor_amd.trainer import Trainer
     P = S.make_train_params(S.make_params("IAN", 1))
     X, Z = S.make_images(B, seed=60), S.make_latents(B, seed=70)
     eps = np.random.RandomState(80).randn(B, 100).astype(np.float32)
     runs = {}
     for ov in (0, 1):
-        ct = CTrainer(CFG, P, B)
+        ct = Trainer(CFG, P, B)
         ct.set_option("overlap_wgrad", ov)
         for _ in range(2):                                     # cold step, then a warm one on the updated parameters
             ct.step(which, X, Z, eps)

@@ -54,5 +54,5 @@ def test_parity_and_training_step_under_asan_with_guard_bands():
     env = _sanitized_env()
     out = _run(env, ["tests/test_gpu_parity.py", "-m", "gpu", "-k", "golden_encode_decode or brush_gradients_vs_golden or ragged_batches"], 1500)
     assert " passed" in out
-    out = _run(env, ["tests/test_gpu_ctrainer.py", "-m", "gpu", "-k", "host_buffers_only"], 1500)
+    out = _run(env, ["tests/test_gpu_train_step.py", "-m", "gpu", "-k", "host_buffers_only"], 1500)
     assert " passed" in out
