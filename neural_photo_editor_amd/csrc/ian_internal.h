@@ -65,8 +65,11 @@ struct TgParams {
   int CoutPad;
   unsigned x_bytes, w_bytes;  // buffer-descriptor extents (out-of-range offsets read as zero)
   int variant;                // K-loop schedule (kernels_tapgemm.hip)
-  const TgTile* tiles;        // split-K with the combine fused into this launch (counters != nullptr): the tile table ...
-  int* counters;              // ... and one arrival counter per tile (zero between launches); nullptr = separate reduce pass
+  const TgTile* tiles;        // split-K with the combine fused into this launch (fused != 0): the tile table ...
+  int* counters;              // ... and one arrival counter per tile (zero between launches)
+  float* raw;                 // fused == 2: one zero-at-rest accumulation tile per output tile (float atomics)
+  int fused;                  // 0: slabs + a tapgemm_reduce launch; 1: write-through slabs combined by the tile's last arriver;
+                              // 2: atomic accumulation into `raw`, epilogue by the last arriver (kernels_tapgemm.hip)
 };
 
 struct TgReduceParams {
@@ -95,6 +98,12 @@ static inline TgShape tg_shape(int cfg) {
     case TG_128x32: return {128, 32};
     default: return {256, 128};
   }
+}
+
+// tile configurations whose kernel carries the in-launch split-K combine (TgParams::fused != 0): the small 4-wave tiles the
+// batch-1 chains use.  The large tiles are compiled WITHOUT that epilogue (it cost the 256x128 tile 95 spilled VGPRs).
+static inline bool tg_fuse_supported(int cfg) {
+  return cfg == TG_32x128 || cfg == TG_64x64 || cfg == TG_128x64 || cfg == TG_128x32;
 }
 
 // one-image form of the 5x5/s2 transposed conv and of its backward-data (kernels_b1.hip): whole contraction per
@@ -134,7 +143,9 @@ hipError_t launch_deconv_out_nchw(const float* x, const float* w, const float* s
                                   int n, int H, int W, int Cin, int Cout, int act, hipStream_t s);
 hipError_t launch_dense_fwd_gemv(const float* x, const float* w, int K, int nout, const float* scale, const float* shift, int act,
                                  float* y, hipStream_t s);
-hipError_t launch_dense_bwd_gemv(const float* g, const float* wb, int rows, int K, const float* res, float* dz, hipStream_t s);
+// upd_z != nullptr: row j's workgroup also applies the brush update z[j] += cg[0] * (dz[j] * cg[1]) (and mirrors z, dz)
+hipError_t launch_dense_bwd_gemv(const float* g, const float* wb, int rows, int K, const float* res, float* dz, float* upd_z,
+                                 const float* upd_cg, float* z_mirror, float* g_mirror, hipStream_t s);
 hipError_t launch_deconv_out_px(const float* x, const float* w, const float* scale, const float* shift, float* y, float* mirror, int n,
                                 int H, int W, int Cin, int Cout, int act, hipStream_t s);
 

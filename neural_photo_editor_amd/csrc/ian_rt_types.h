@@ -28,6 +28,8 @@ struct Schedule {
   int ntiles = 0;  // >0 => split-K: slabs + reduce pass
   TgTile* d_tiles = nullptr;
   int* d_counters = nullptr;   // split-K combine fused into the tapgemm launch: one arrival counter per tile (zero at rest)
+  float* d_raw = nullptr;      // fused == 2: one accumulation tile per output tile (zero at rest)
+  int fused = 0;               // how this schedule's split-K partials are combined (TgParams::fused)
   size_t slab_tiles = 0;
   int max_nsplit = 1;
   std::vector<TgItem> h_items;  // kept for tests / debugging
@@ -38,6 +40,7 @@ struct TgChoice {  // autotuned (or forced) schedule shape for one (layer, batch
   int cfg = -1;        // enum TgConfig, -1 = heuristic
   int max_steps = -1;  // -1 = heuristic, 0 = never split K, >0 = split so that no item exceeds this many K-steps
   int variant = -1;    // K-loop schedule of tapgemm_kernel, -1 = the handle's option
+  int fused = -1;      // split-K combine: -1 = the handle's option (tg_fuse for small M), 0 reduce launch, 1 in-launch slabs, 2 atomics
 };
 
 // one linear map executed by the tapgemm kernel (forward or backward-data form of an op)
@@ -103,11 +106,18 @@ struct Options {
   int tg_nosplit_min_out = 1 << 30;  // outputs (M*Cout) above which 64x64 is forced even if it under-fills
   int mdc_head = 2;                  // few-filter MDCL layers: 0 = tapgemm, 1 = VALU head kernel, 2 = + sibling layers fused
   int tg_variant = 2;                // K-loop schedule of tapgemm_kernel (kernels_tapgemm.hip); autotune picks per layer
-  int tg_fused_reduce_max_m = 0;     // split-K combine by the last-arriving workgroup (no reduce launch) when images*QH*QW <= this.
-                                     // OFF: measured 3x slower per layer at batch 1 (14 -> 37-48 us) -- the agent-scope release every
-                                     // workgroup needs before it bumps the arrival counter is a whole-L2 writeback on gfx950
+  int tg_fuse = 0;                   // split-K combine of launches with images*QH*QW <= tg_fuse_max_m (the batch-1 chains, where a reduce launch
+                                     // costs as much as the K loop): 0 = separate tapgemm_reduce launch; 1 = write-through (sc1) slabs summed by
+                                     // the tile's last-arriving workgroup in slice order (deterministic); 2 = float atomics into a zero-at-rest
+                                     // tile + epilogue by the last arriver (run-to-run last-bit differences).  The autotuner may pick per layer.
+  int tg_fuse_max_m = 1024;
+  int tg_fuse_tune = 0;              // fused modes ian_autotune may try for such launches: 0 none, 1 = mode 1, 2 = modes 1 and 2.  OFF: measured on
+                                     // MI355X (profiles/r05_b1_inlaunch_combine_ab.json) the autotuner kept the reduce launch for every 5x5 layer, and
+                                     // the fused modes forced on untuned layers cost +13 us (mode 1) / +9 us (mode 2) per layer
   int tg_reduce_kp = 4;              // split-K reduce: lanes sharing one output element's slabs when a tile has >= 8 slabs
   int wg_w8 = 1;                     // tapwgrad: 8-wave 128x128 workgroups (16 waves per CU instead of 8)
+  int wg_xcd_split = 1;              // tapwgrad: all items of one pixel range go to one XCD (its rows are fetched into that L2 once), split count a
+                                     // multiple of 8 (round 5); 0 = round 4's (split, tap) order
   int wg_target_items = 1024;        // tapwgrad: split the pixel range until taps x channel tiles x splits reaches this many workgroups
   int mdc_thin_tile = 1;             // thin MDCL (G_b / B_b and their backward-data) with the input rows staged through LDS
   int b1_conv = 0;                   // batch-1 transposed convs and their backward-data as whole-contraction streaming launches
@@ -118,6 +128,7 @@ struct Options {
   int dense_gemv = 1;                // batch-1 backward of the dense layer fed by the latent as one GEMV launch
   int dec_out_px = 1;                // ... and, below that batch, 8 lanes per output pixel instead of 16 tile workgroups
   int dec_out_mfma = 1;              // image-producing deconv (IAN_simple dec_out) on the matrix cores for batches >= 4
+  int fuse_latent_update = 1;        // ian_brush_step: the latent update rides in the epilogue of the latent's backward GEMV (round 5)
   int edit_graph = 1;                // batch-1 host-pointer calls (the NPE edit loop) replay captured hipGraphs
   int edit_spin = 1;                 // ... and their final wait polls the stream (hipStreamQuery) before it falls back to hipStreamSynchronize
   int edit_zero_copy = 1;            // their kernels read the brush rectangle from / write z, dz, the image to the pinned block directly
@@ -198,6 +209,9 @@ struct ian_handle {
   // boundary on this runtime: four of them per brush event.
   float* pin_dev = nullptr;
   float* out_mirror = nullptr;   // set around run_segment(DEC): the batch-1 image kernel also writes the image there
+  // set around run_decoder_backward by ian_brush_step: the latent's backward GEMV also applies Z += coef * (dZ * gscale) (one launch
+  // less per brush event); done = the fused form was taken (else the caller launches latent_update_kernel)
+  struct { const float* cg = nullptr; float* z_mirror = nullptr; float* g_mirror = nullptr; bool done = false; } upd;
   bool pin_img_valid = false;    // pin[PIN_IMG..] holds the image that is resident in the output slot
   int* d_patch = nullptr;
   EditGraph g_fwd, g_bwd[2], g_step[2][2];   // g_step[mode][image wanted]: backward + latent update + forward (ian_brush_step)

@@ -100,6 +100,10 @@ __global__ __launch_bounds__(256) void conv1_nchw_kernel(const float* __restrict
 // the wave's 76x32 filter block lives in 38 registers and serves C1M_ROWS output rows.  The staged rows are stored
 // de-interleaved by column parity (even columns, then odd columns): the stride-2 gather "column 2*ox + kx" of the 32
 // lanes becomes a contiguous read (round 1 measured 47.6 % bank-conflict cycles on the interleaved image).
+// Round 5 measured a pipelined variant of the kernel below (filter block requested before the image rows, two row pairs per
+// workgroup with the next pair's rows in flight under the MFMAs, patch operands read from LDS a group of 8 k-pairs ahead):
+// 24.7 us against 21.8-22.2 us for this form at batch 64 (gpurun_out/r05b traces) -- 199 VGPRs halve the resident waves and the
+// lock-step prologue is not what bounds it.  The layer's floor is 8.0 us of exact-fp32 matrix work (1.26 GFLOP at 157 TF/s).
 typedef float c1_f32x16 __attribute__((ext_vector_type(16)));
 constexpr int C1M_ROWS = 2;   // 4 rows per block measured slower (34 vs 23 us at batch 64): fewer, longer latency chains
 template <int COUT>
@@ -493,8 +497,24 @@ hipError_t launch_deconv_out_bwd(const float* g, const float* w, float* dx, cons
 // Batch-1 backward-data of the dense layer that consumes the latent (l_dec_fc2, IAN_simple.py:112-121; the last step of
 // API.py:59,64's T.grad): dz[j] = sum_k g[k] * Wb[j][k].  One workgroup per latent row j streams its 32 KB weight row with
 // every load in flight at once -- one launch instead of a split-K tap GEMM, its reduce pass and a row copy.
+// upd (ian_brush_step, NPE.py:205-209 / 313-314): the workgroup that owns latent row j also applies the brush update
+// Z[j] += coef * (dZ[j] * gscale) -- float32, every product rounded on its own, in the reference's order: bit-identical to the numpy
+// expression and to latent_update_kernel (kernels_npe.hip), the separate launch this replaces in the captured brush event.  No
+// other workgroup of this launch reads Z[j], and the next kernel of the chain (the decoder's first layer) reads the new row.
+struct LatentUpd {
+  float* z;          // the latent row, updated in place (nullptr: no update)
+  const float* cg;   // (coef, gscale), device-readable
+  float* z_mirror;   // or nullptr: the new latent ...
+  float* g_mirror;   // ... and the gradient also go there (the pinned host block, zero-copy)
+};
+__device__ __forceinline__ float latent_step(float z, float g, float coef, float gscale) {
+#pragma clang fp contract(off)
+  float t = g * gscale;
+  t = coef * t;
+  return z + t;
+}
 __global__ __launch_bounds__(256) void dense_bwd_gemv_kernel(const float* __restrict__ g, const float* __restrict__ wb, int K,
-                                                             const float* __restrict__ res, float* __restrict__ dz) {
+                                                             const float* __restrict__ res, float* __restrict__ dz, LatentUpd upd) {
   __shared__ float part[4];
   const int row = blockIdx.x;
   const float* wr = wb + (size_t)row * K;
@@ -513,8 +533,15 @@ __global__ __launch_bounds__(256) void dense_bwd_gemv_kernel(const float* __rest
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float v = (part[0] + part[1]) + (part[2] + part[3]);
-    dz[row] = res ? v + res[row] : v;
+    float v = (part[0] + part[1]) + (part[2] + part[3]);
+    if (res) v += res[row];
+    dz[row] = v;
+    if (upd.z) {
+      const float zn = latent_step(upd.z[row], v, upd.cg[0], upd.cg[1]);
+      upd.z[row] = zn;
+      if (upd.z_mirror) upd.z_mirror[row] = zn;
+      if (upd.g_mirror) upd.g_mirror[row] = v;
+    }
   }
 }
 // Batch-1 forward of a dense layer fed by a short vector (l_dec_fc2: 100 -> 8192): y[o] = act(scale[o] * sum_k x[k] W[o][k]
@@ -549,9 +576,11 @@ hipError_t launch_dense_fwd_gemv(const float* x, const float* w, int K, int nout
   return hipGetLastError();
 }
 
-hipError_t launch_dense_bwd_gemv(const float* g, const float* wb, int rows, int K, const float* res, float* dz, hipStream_t s) {
+hipError_t launch_dense_bwd_gemv(const float* g, const float* wb, int rows, int K, const float* res, float* dz, float* upd_z,
+                                 const float* upd_cg, float* z_mirror, float* g_mirror, hipStream_t s) {
   if (K & 3) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(dense_bwd_gemv_kernel, dim3(rows), dim3(256), 0, s, g, wb, K, res, dz);
+  const LatentUpd u{upd_z, upd_cg, z_mirror, g_mirror};
+  hipLaunchKernelGGL(dense_bwd_gemv_kernel, dim3(rows), dim3(256), 0, s, g, wb, K, res, dz, u);
   return hipGetLastError();
 }
 

@@ -98,6 +98,13 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigne
   return r;
 }
 
+// native global_atomic_add_f32, no return value (performed at the memory side: coherent across the XCDs' L2s)
+__device__ __forceinline__ void tg_atomic_add(float* p, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)__builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)p, v);
+#endif
+}
+
 template <int FM, int FN>
 __device__ __forceinline__ void tg_compute(const float* a_s, const float* b_s, f32x16 (&acc)[FM][FN]) {
 #pragma unroll
@@ -477,50 +484,11 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
 
   // ---- epilogue. C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
   if (it.slab >= 0) {
-    float* sl = p.slab + (size_t)it.slab * (BM * BN);
-    const int col_l = lane & 31;
-    const int rhalf = 4 * (lane >> 5);
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-          const int col = wn * (BN / WN) + j * 32 + col_l;
-          sl[row * BN + col] = acc[i][j][r];
-        }
-#ifndef IAN_ABLATION
-    return;   // a tapgemm_reduce launch follows
-#else
-    if (!p.counters) return;   // a tapgemm_reduce launch follows
-    // (libian_ablation.so only: measured 3x SLOWER per layer at batch 1 -- the agent-scope release every workgroup executes is a
-    // whole-L2 write-back on this part)
-    // ---- split-K combine by the workgroup that arrives last at the tile (no second launch: at batch 1 a launch
-    // boundary costs as much as the K loop).  Every partial is fenced to the device before the arrival counter is
-    // bumped; the last arriver re-reads ALL slabs of the tile, its own included, in slab order -> the sum does not
-    // depend on who arrives last.  The counter is back at zero when the launch ends.
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    const TgTile tl = p.tiles[it.tile];
-    if (tid == 0) {
-      const int ticket = atomicAdd(&p.counters[it.tile], 1);
-      s_last = (ticket == tl.nsplit - 1);
-      if (s_last) p.counters[it.tile] = 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const float* s0 = p.slab + (size_t)tl.slab0 * (BM * BN);
-    for (int k = 0; k < tl.nsplit; ++k) {
-      const float* sk = s0 + (size_t)k * (BM * BN);
+    constexpr bool FUSE = WM * WN == 4 && BM * BN <= 128 * 64;   // == tg_fuse_supported(cfg): the host never asks the others
+    if (!FUSE || p.fused == 0) {   // split-K, separate reduce launch: row-major slab tile
+      float* sl = p.slab + (size_t)it.slab * (BM * BN);
+      const int col_l = lane & 31;
+      const int rhalf = 4 * (lane >> 5);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -529,10 +497,106 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
           for (int r = 0; r < 16; ++r) {
             const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
             const int col = wn * (BN / WN) + j * 32 + col_l;
-            acc[i][j][r] += __builtin_nontemporal_load(sk + row * BN + col);
+            sl[row * BN + col] = acc[i][j][r];
+          }
+      return;   // a tapgemm_reduce launch follows
+    }
+    // ---- split-K combined INSIDE this launch (round 5; batch-1 chains: the reduce launch costs as much as the K loop there).
+    // The partial tile travels in FRAGMENT order -- quad (i, j, rq) of a wave = accumulator registers 4 rq .. 4 rq + 3 = rows
+    // 8 rq .. 8 rq + 7 of its 32 x 32 block, one 16-byte vector per lane, lanes contiguous -- so every access below is a fully
+    // coalesced dwordx4; quads whose 8 rows all lie beyond M (batch 1: half of a 32-row tile) are skipped on both sides.
+    //   fused 1: every slice writes its slab WRITE-THROUGH (sc1 stores reach the fabric: no L2 write-back fence needed), drains
+    //            its stores (vmcnt(0)), takes a ticket; the last arriver of the tile re-reads ALL slabs with sc1 loads, its own
+    //            included, in slice order -> deterministic whoever is last (MI355X_MICROARCH.md rows publish-large, splitk-seam;
+    //            the round-2 attempt used plain stores + __threadfence() in every thread: 3x slower per layer).
+    //   fused 2: every slice ADDS its partial into one zero-at-rest raw tile with float atomics (performed at the memory side);
+    //            the last arriver reads that ONE tile, zeroes it again and applies the epilogue.  No slab walk, but the summation
+    //            order is the arrival order: results vary in the last bits from run to run (an option, never the default).
+    if constexpr (FUSE) {
+    const TgTile tl = p.tiles[it.tile];
+    constexpr int QV = FM * FN * 4;                       // 16-byte vectors per lane per wave tile
+    constexpr size_t TILE_V = (size_t)WM * WN * QV * 64;  // float4 vectors per slab tile ( == BM * BN / 4 )
+    float4* base = reinterpret_cast<float4*>(p.fused == 1 ? p.slab + (size_t)it.slab * (BM * BN) : p.raw + (size_t)it.tile * (BM * BN));
+    const size_t wv = ((size_t)wave * QV) * 64 + lane;
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(base), 0, (unsigned)(TILE_V * 16), 0x00020000);
+    bool live[FM][4];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) live[i][rq] = it.m0 + wm * (BM / WM) + i * 32 + 8 * rq < p.M;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          if (!live[i][rq]) continue;
+          const unsigned voff = (unsigned)((wv + (size_t)((i * FN + j) * 4 + rq) * 64) * 16);
+          if (p.fused == 1) {
+            u32x4 v;
+            v.x = __float_as_uint(acc[i][j][4 * rq + 0]); v.y = __float_as_uint(acc[i][j][4 * rq + 1]);
+            v.z = __float_as_uint(acc[i][j][4 * rq + 2]); v.w = __float_as_uint(acc[i][j][4 * rq + 3]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, srsrc, voff, 0, /*aux: sc1 = write-through*/ 16);
+          } else {
+            float* q = reinterpret_cast<float*>(base) + (voff >> 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tg_atomic_add(q + e, acc[i][j][4 * rq + e]);
+          }
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores / atomics have been performed ...
+    __syncthreads();                                      // ... and so have every other wave's of the workgroup
+    int* flag = reinterpret_cast<int*>(smem);             // the LDS tiles are dead: reuse their first word (no second __shared__ object)
+    if (tid == 0) {
+      const int ticket = __hip_atomic_fetch_add(&p.counters[it.tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == tl.nsplit - 1;
+      if (last) __hip_atomic_store(&p.counters[it.tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero at rest
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // drop this CU's L1 (the slab lines it may hold are stale); the loads below are sc1
+    if (p.fused == 1) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      const unsigned slab_stride = (unsigned)(TILE_V * 16);
+      // slabs of one tile are consecutive; walk them two at a time (2 x QV vectors in flight per lane), summing in slice order
+      const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
+          p.slab + (size_t)tl.slab0 * (BM * BN), 0, (unsigned)((size_t)tl.nsplit * TILE_V * 16), 0x00020000);
+      for (int k = 0; k < tl.nsplit; ++k) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+              if (!live[i][rq]) continue;
+              const unsigned voff = (unsigned)((wv + (size_t)((i * FN + j) * 4 + rq) * 64) * 16);
+              const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(trsrc, voff, (unsigned)k * slab_stride, /*sc1*/ 16);
+              acc[i][j][4 * rq + 0] += __uint_as_float(v.x); acc[i][j][4 * rq + 1] += __uint_as_float(v.y);
+              acc[i][j][4 * rq + 2] += __uint_as_float(v.z); acc[i][j][4 * rq + 3] += __uint_as_float(v.w);
+            }
+      }
+    } else {
+      const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            if (!live[i][rq]) continue;
+            const unsigned voff = (unsigned)((wv + (size_t)((i * FN + j) * 4 + rq) * 64) * 16);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srsrc, voff, 0, /*sc1*/ 16);
+            acc[i][j][4 * rq + 0] = __uint_as_float(v.x); acc[i][j][4 * rq + 1] = __uint_as_float(v.y);
+            acc[i][j][4 * rq + 2] = __uint_as_float(v.z); acc[i][j][4 * rq + 3] = __uint_as_float(v.w);
+            __builtin_amdgcn_raw_buffer_store_b128(zero4, srsrc, voff, 0, /*sc1*/ 16);   // zero at rest for the next launch
           }
     }
-#endif
+    }  // FUSE
   }
   tg_store<BM, BN, WM, WN>(p, it, cl, acc, wm, wn, lane);
 }

@@ -779,7 +779,7 @@ class Trainer:
             self.lib.ian_trainer_destroy(self._h)
             self._h = C.c_void_p()
             if getattr(self, "_ops", None) is not None:      # the communicators die after the trainer that used their table
-                self.comm.close()
+                getattr(self.comm, "close", lambda: None)()
                 self._ops = None
 
     def __del__(self):

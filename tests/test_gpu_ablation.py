@@ -1,6 +1,6 @@
 """The measured NEGATIVE results stay runnable, but outside the product: `IAN_ABLATION_BUILD=1` builds libian_ablation.so from
 the same sources with -DIAN_ABLATION -- tapgemm K-loop schedules 0 (compiler-scheduled) and 3 (LDS-DMA staging, 5 % slower),
-the in-launch split-K combine (3x slower per batch-1 layer), the batch-1 streaming deconv of kernels_b1.hip (slower) and the
+the batch-1 streaming deconv of kernels_b1.hip (slower) and the
 superseded 4-wave tapwgrad tile (round-3 verdict, weak #10).  libian.so contains none of them and rejects their option values
 (checked by the skipping branch of the same tests in the normal run).  Here a child Python runs those parity / bitwise tests
 against the ablation library (IAN_LIB), so the variants cannot rot."""
@@ -41,7 +41,7 @@ def test_ablation_library_builds_and_says_what_it_is():
 @pytest.mark.gpu
 def test_negative_result_variants_still_pass_their_parity_tests():
     env = _ablation_env()
-    sel = ("every_tile_config_and_split_policy or split_k_combine_fused_vs_reduce_pass or batch1_streaming_deconv_equals_the_tapgemm_form "
+    sel = ("every_tile_config_and_split_policy or batch1_streaming_deconv_equals_the_tapgemm_form "
            "or eight_wave_tile_is_bitwise_the_four_wave_tile")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider", "-m", "gpu", "-rs", "tests/test_gpu_parity.py",
                         "tests/test_gpu_train_kernels.py", "-k", sel], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,

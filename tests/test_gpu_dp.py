@@ -4,7 +4,7 @@ Two ranks share cuda:0 over gloo (RCCL needs one GPU per rank; the collective ca
 ranks and the single process run the SAME C++ sequencer (csrc/ian_trainer.cpp); the collectives reach it through the
 ian_comm_ops callback table filled from torch.distributed (trainer.Comm.ops)."""
 import os
-import socket
+import sys
 
 import numpy as np
 import pytest
@@ -12,128 +12,29 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CFG = os.path.join(ROOT, "neural_photo_editor_amd", "configs", "IAN.py")
-B = 4
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dp_rehearsal  # noqa: E402  (tests/dp_rehearsal.py: the worker, shared with scripts/exp/config5_rehearsal.py)
 
 
-def _inputs():
-    from oracle import ian_oracle as O
-    X = O.make_images(B, seed=3)
-    s = np.array([0.2, 0.5, 0.8, 1.0], np.float32).reshape(-1, 1, 1, 1)
-    o = np.array([-0.5, 0.3, -0.1, 0.0], np.float32).reshape(-1, 1, 1, 1)
-    X = np.clip(X * s + o, -1, 1).astype(np.float32)       # well separated samples (see test_gpu_train.diverse_images)
-    Z = O.make_latents(B, seed=8)
-    eps = np.random.RandomState(9).randn(B, 100).astype(np.float32)
-    # images fed to the encoder passes on X_hat / X_gen (Trainer.forward test hook): a random-init decoder emits
-    # near-identical images, for which the MinibatchLayer's |a_b - a_b'| gradients flip sign under 1e-7 perturbations
-    # (such as a different partial-sum order of the batch statistics); well separated images keep the comparison sharp
-    Xh = np.clip(O.make_images(B, seed=4)[::-1] * s + o, -1, 1).astype(np.float32)
-    Xg = np.clip(np.roll(O.make_images(B, seed=5), 1, 0) * s[::-1] + o, -1, 1).astype(np.float32)
-    return X, Z, eps, Xh, Xg
-
-
-def _worker(rank, world, port, out_dir):
-    import torch
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from oracle import ian_oracle as O
-        from oracle.train_twin import make_train_params
-        from neural_photo_editor_amd.trainer import Trainer, Comm
-        torch.cuda.set_device(0)
-        P = make_train_params(O.make_params("IAN", 1))
-        tr = Trainer(CFG, P, batch=B // world, comm=Comm(), exact=True)
-        assert tr.N == B and tr.exact
-        X, Z, eps, Xh, Xg = _inputs()
-        n = B // world
-        sl = slice(rank * n, (rank + 1) * n)
-        d = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl])).cuda()
-        res = {}
-        for which in ("gen", "discrim"):
-            upd = "dec" if which == "gen" else "enc"
-            # first sweep of this kind: the gradient-write order is recorded, buckets are reduced after backward
-            tr.forward(d(X), d(Z), d(eps), xhat_override=d(Xh), xgen_override=d(Xg))
-            m = tr.metrics()
-            tr.backward(which)
-            tr._finish_allreduce(which)
-            torch.cuda.synchronize()
-            first = {g: tr.groups[g].g.clone() for g in (upd, "Z")}
-            n_first = len(tr.overlap_log)
-            # second sweep, same inputs and parameters: every bucket is handed to the all-reduce right after its last
-            # writer, while backward is still being issued
-            tr.forward(d(X), d(Z), d(eps), xhat_override=d(Xh), xgen_override=d(Xg))
-            tr.backward(which)
-            tr._finish_allreduce(which)
-            torch.cuda.synchronize()
-            for g in (upd, "Z"):
-                assert torch.equal(first[g], tr.groups[g].g), "overlapped all-reduce changed the %s gradients" % g
-                res["%s/%s" % (which, g)] = tr.groups[g].g.cpu().numpy()
-            log = list(tr.overlap_log)[n_first:]
-            assert len(log) == tr.plan_size(which) and all(r["which"] == which for r in log)
-            early = [r for r in log if r["issued_at_write"] < r["writes_in_backward"]]
-            res["%s/early" % which] = np.array([len(early), len(log)])
-            zb = [r for r in log if r["bucket"][0] == "Z"]
-            assert zb and all(r["issued_at_write"] < 0.8 * r["writes_in_backward"] for r in zb), zb   # Z_params: long before the end
-            assert len(early) >= len(log) - 1, log     # at most the bucket holding the very last written tensor waits for the end
-            res["%s/metrics" % which] = np.array([m[k] for k in sorted(m)])
-        if rank == 0:
-            np.savez(os.path.join(out_dir, "dp.npz"), **res)
-    finally:
-        dist.destroy_process_group()
-
-
-def test_two_rank_step_equals_single_process_step(tmp_path, monkeypatch):
-    # Split-K schedules are a function of the per-rank batch (2 images here, 4 in the single process): with them on, the
-    # same image's activations differ in the last bit between the two runs and a handful of leaky-ReLU branches flip
-    # (measured: up to 5e-4 on a few tensors).  The collectives are what this test is about: pin the schedules so that
-    # every per-image result is bitwise batch-size independent, and hold the comparison to float32 summation noise.
+# (world, global batch): the round-1..4 case, and a world-4 x 32 images version of BASELINE.json configs[4] (8 x 128 = 1024 runs as
+# scripts/exp/config5_rehearsal.py -> profiles/r05_config5_rehearsal.json: ~4 GPU-minutes, outside the suite's budget)
+@pytest.mark.parametrize("world,B", [(2, 4), (4, 128)])
+def test_sharded_step_equals_single_process_step(world, B, tmp_path, monkeypatch):
+    # Split-K schedules are a function of the per-rank batch: with them on, the same image's activations differ in the last bit
+    # between the two runs and a handful of leaky-ReLU branches flip (measured: up to 5e-4 on a few tensors).  The collectives are
+    # what this test is about: pin the schedules so that every per-image result is bitwise batch-size independent, and hold the
+    # comparison to float32 summation noise.
     monkeypatch.setenv("IAN_OPTS", "tg_split=0")
-    import torch
-    import torch.multiprocessing as mp
-    from oracle import ian_oracle as O
-    from oracle.train_twin import make_train_params
-    from neural_photo_editor_amd.trainer import Trainer
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(timeout=600)
-        assert p.exitcode == 0
-    dp = np.load(str(tmp_path / "dp.npz"))
-    P = make_train_params(O.make_params("IAN", 1))
-    tr = Trainer(CFG, P, batch=B)
-    X, Z, eps, Xh, Xg = _inputs()
-    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    # relative L2 error per tensor.  The batch statistics are rank-order invariant (per-image chunks + pairwise tree,
-    # kernels_train.hip / Comm.all_reduce_sum_ordered), so the forward activations of the two runs are IDENTICAL and no
-    # leaky-ReLU / |.| branch can flip; what remains is the float32 summation order of the weight gradients (per-rank
-    # partial sums added by the all-reduce vs one sum over the whole minibatch): ~1e-7 relative.
-    rel = lambda a, b: float(np.linalg.norm((a - b).astype(np.float64)) / (np.linalg.norm(b.astype(np.float64)) + 1e-30))
-    diag = {}
+    dp = dp_rehearsal.run_ranks(world, B, tmp_path)
     for which in ("gen", "discrim"):
-        tr.forward(d(X), d(Z), d(eps), xhat_override=d(Xh), xgen_override=d(Xg))
-        m = tr.metrics()
-        tr.backward(which)
-        tr._finish_allreduce(which)          # world 1: joins the weight-gradient stream (no collective)
-        assert np.allclose(dp["%s/metrics" % which], np.array([m[k] for k in sorted(m)]), rtol=1e-5, atol=1e-6)
         assert dp["%s/early" % which][0] >= 1
-        for g in (("dec" if which == "gen" else "enc"), "Z"):
-            ref = tr.groups[g].g.cpu().numpy()
-            grp = tr.groups[g]
-            errs = sorted(((rel(dp["%s/%s" % (which, g)][o:o + c], ref[o:o + c]), n) for n, (o, c, _) in grp.offsets.items()), reverse=True)
-            diag["%s/%s" % (which, g)] = errs[:4]
-    _diag("dp_two_rank_vs_single", diag)
-    # measured on MI355X (gpurun_out/diag/dp_two_rank_vs_single.json): <= 1e-5 for every tensor, worst on the 2-element
-    # MDCL coefficient gradients (<dS, W> inner products of ~10^5 terms whose partial sums differ between the two runs)
+    diag = dp_rehearsal.single_process_errors(dp, B)
+    _diag("dp_%dx%d_vs_single" % (world, B // world), {k: (v[:4] if isinstance(v, list) else v) for k, v in diag.items()})
+    # measured on MI355X (gpurun_out/diag/dp_*_vs_single.json): <= 1e-5 for every tensor at 2 x 2, worst on the 2-element MDCL
+    # coefficient gradients (<dS, W> inner products of ~10^5 terms whose partial sums differ between the two runs)
     for key, errs in diag.items():
-        assert errs[0][0] < 3e-5, (key, errs)
+        if isinstance(errs, list):
+            assert errs[0][0] < 3e-5, (key, errs[:4])
 
 
 def test_batch_statistics_are_bitwise_rank_order_invariant():
@@ -166,31 +67,43 @@ def test_batch_statistics_are_bitwise_rank_order_invariant():
 
 def test_native_rccl_collective_table_single_rank():
     """csrc/ian_comm_rccl.cpp: the ian_comm_ops table filled from librccl itself (dlopen), exercised as far as ONE GPU allows: a
-    1-rank communicator whose all-reduce and all-gather are identities on the trainer's kind of buffers and streams, wait_all
-    orders a compute stream behind the side stream the all-reduce ran on, and the table is accepted by ian_trainer_set_comm.
+    1-rank pair of communicators (all-reduce; all-gather on its own one) whose collectives are identities on the trainer's kind of
+    buffers and streams; wait_all orders the compute stream behind EVERY side stream an all-reduce was issued on since the last
+    wait (round 4 recorded the last one only), and the table is accepted by ian_trainer_set_comm.
     (RCCL refuses two ranks on one device: the multi-rank step is covered with the torch.distributed filler over gloo above.)"""
     import ctypes as C
     import torch
     from neural_photo_editor_amd import trainer as T
     comm = T.NativeRcclComm()
     assert comm.world == 1
-    ops = comm.ops(torch)
+    ops = comm.ops(torch)                                      # comm_create + add_gather
     try:
-        assert (ops.world, ops.rank) == (1, 0) and ops.ctx
-        side, main = torch.cuda.Stream(), torch.cuda.current_stream()
-        x = torch.randn(1 << 20, device="cuda")
-        want = x.clone()
+        assert (ops.world, ops.rank) == (1, 0) and ops.ctx and comm.filler.startswith("librccl")
+        side_a, side_b, main = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()
+        x = torch.randn(1 << 22, device="cuda")
+        y = torch.randn(1 << 22, device="cuda")
+        wx, wy = x.clone(), y.clone()
         torch.cuda.synchronize()
-        assert ops.allreduce_sum(ops.ctx, x.data_ptr(), x.numel(), side.cuda_stream) == 0      # sum over one rank
+        # two side streams, each kept busy by a long chain first, so that a wait_all that orders only ONE of them lets the consumer
+        # below read the other buffer before its stream got there
+        for st, buf in ((side_a, x), (side_b, y)):
+            with torch.cuda.stream(st):
+                for _ in range(200):
+                    buf.mul_(1.0)
+                buf.add_(1.0)
+            assert ops.allreduce_sum(ops.ctx, buf.data_ptr(), buf.numel(), st.cuda_stream) == 0      # sum over one rank
         assert ops.wait_all(ops.ctx, main.cuda_stream) == 0
-        y = x * 2                                                                                  # ordered behind the collective
+        z = x * 2 + y                                                                              # ordered behind BOTH collectives
         torch.cuda.synchronize()
-        assert torch.equal(x, want) and torch.equal(y, want * 2)
+        assert torch.equal(x, wx + 1) and torch.equal(y, wy + 1) and torch.equal(z, (wx + 1) * 2 + (wy + 1))
+        assert ops.wait_all(ops.ctx, main.cuda_stream) == 0                                        # nothing pending: no-op
         dst = torch.zeros_like(x)
         assert ops.allgather(ops.ctx, x.data_ptr(), dst.data_ptr(), x.numel(), main.cuda_stream) == 0
         torch.cuda.synchronize()
-        assert torch.equal(dst, want)
+        assert torch.equal(dst, wx + 1)
         assert ops.allreduce_sum(ops.ctx, 0, 16, 0) != 0                                           # null buffer: an error code, no crash
+        lib = comm._lib
+        assert lib.ian_rccl_comm_add_gather(C.byref(ops), C.create_string_buffer(128)) == -6       # a second gather communicator: refused
     finally:
         comm.close()
     assert ops.ctx is None

@@ -123,9 +123,19 @@ def test_every_tile_config_and_split_policy(cfg):
         m.handle.set_option("tg_target_items", 4096)   # aggressive split-K
         m.handle.set_option("tg_min_steps", 1)
         m.handle.set_option("tg_split", 1)
-        assert rel(m.reconstruct(x), ref) < TOL
+        base = m.reconstruct(x)
+        assert rel(base, ref) < TOL
+        # ... combined inside the launch (tg_fuse 1: write-through slabs + last arriver, reproducible; 2: float atomics) wherever
+        # the tile carries that epilogue (the small 4-wave tiles; the others silently keep the reduce launch): launches of
+        # images*QH*QW <= 1024 rows -- at 3 images every layer but enc_conv1
+        for mode in (1, 2):
+            m.handle.set_option("tg_fuse", mode)
+            a, b = m.reconstruct(x), m.reconstruct(x)
+            assert rel(a, ref) < TOL and rel(a, base) < 1e-5, mode
+            if mode == 1:
+                assert np.array_equal(a, b)
     finally:
-        for k, v in (("tg_cfg", -1), ("tg_split", 1), ("tg_target_items", 768), ("tg_min_steps", 16), ("tg_variant", 2)):
+        for k, v in (("tg_cfg", -1), ("tg_split", 1), ("tg_target_items", 768), ("tg_min_steps", 16), ("tg_variant", 2), ("tg_fuse", 0)):
             m.handle.set_option(k, v)
 
 
@@ -324,7 +334,7 @@ def _needs_ablation_library():
     from neural_photo_editor_amd.lib import is_ablation_build
     if not is_ablation_build():
         m, _, _ = model_for("IAN_simple")
-        for key, val in (("tg_fused_reduce_max_m", 1024), ("b1_conv", 1), ("tg_variant", 0), ("tg_variant", 3)):
+        for key, val in (("b1_conv", 1), ("tg_variant", 0), ("tg_variant", 3)):
             with pytest.raises(Exception):
                 m.handle.set_option(key, val)                 # the product library refuses them loudly
         pytest.skip("variant compiled into libian_ablation.so only (see tests/test_gpu_ablation.py)")
@@ -332,30 +342,37 @@ def _needs_ablation_library():
 
 @pytest.mark.parametrize("arch", O.ARCHS)
 def test_split_k_combine_fused_vs_reduce_pass(arch):
-    """Split-K partial sums combined by the last-arriving workgroup inside the tapgemm launch (tg_fused_reduce_max_m > 0;
-    selectable, off by default: slower on gfx950) vs the separate reduce pass: both match the oracle,
-    the fused one is reproducible run to run (the sum order is the slab order, whoever arrives last)."""
-    _needs_ablation_library()
+    """Round 5: split-K partial sums combined INSIDE the tapgemm launch for the small launches of the batch-1 chains
+    (kernels_tapgemm.hip, tg_fuse): mode 1 = write-through (sc1) slabs summed by the tile's last-arriving workgroup in slice order
+    -- reproducible run to run whoever arrives last, which is also the sharp test of the hand-off itself (a stale slab line would
+    change bits between repetitions); mode 2 = float atomics into a zero-at-rest tile + epilogue by the last arriver -- within
+    round-off of the others, not bitwise.  Both match the oracle and the separate reduce pass (mode 0), forward and latent-brush
+    backward, under aggressive split-K (tens of slabs per tile) and repeated 25 times back to back (uneven arrival orders)."""
     m, orc, P = model_for(arch)
-    x = O.make_images(2, seed=91)
+    x = O.make_images(1, seed=91)
     z = O.make_latents(1, seed=92)
     want = orc.reconstruct(x)
+    os.environ["IAN_NO_DEC_CACHE"] = "1"
+    out = {}
     try:
         m.handle.set_option("tg_target_items", 4096)   # aggressive split-K: tens of slabs per tile
         m.handle.set_option("tg_min_steps", 1)
-        m.handle.set_option("tg_fused_reduce_max_m", 1024)
-        a = [m.reconstruct(x) for _ in range(3)]
-        ga = [m.imgradRGB(10, 20, 30, 40, red_rgb(), z) for _ in range(3)]
-        m.handle.set_option("tg_fused_reduce_max_m", 0)
-        b = m.reconstruct(x)
-        gb = m.imgradRGB(10, 20, 30, 40, red_rgb(), z)
+        for mode in (1, 2, 0):
+            m.handle.set_option("tg_fuse", mode)
+            out[mode] = ([m.reconstruct(x) for _ in range(25)], [m.imgradRGB(10, 20, 30, 40, red_rgb(), z) for _ in range(25)])
     finally:
-        for k, v in (("tg_target_items", 768), ("tg_min_steps", 16), ("tg_fused_reduce_max_m", 0)):
+        del os.environ["IAN_NO_DEC_CACHE"]
+        for k, v in (("tg_target_items", 768), ("tg_min_steps", 16), ("tg_fuse", 0)):
             m.handle.set_option(k, v)
-    assert rel(a[0], want) < TOL and rel(b, want) < TOL
-    assert np.array_equal(a[0], a[1]) and np.array_equal(a[0], a[2])
-    assert np.array_equal(ga[0], ga[1]) and np.array_equal(ga[0], ga[2])
-    assert rel(a[0], b) < 1e-5 and rel(ga[0], gb) < 1e-4
+    for mode in (0, 1):
+        assert all(np.array_equal(out[mode][0][0], a) for a in out[mode][0]), "mode %d: reconstruction not reproducible" % mode
+        assert all(np.array_equal(out[mode][1][0], g) for g in out[mode][1]), "mode %d: gradient not reproducible" % mode
+    for mode in (0, 1, 2):
+        assert max(rel(a, want) for a in out[mode][0]) < TOL, mode
+        assert max(rel(a, out[0][0][0]) for a in out[mode][0]) < 1e-5, mode
+        assert max(rel(g, out[0][1][0]) for g in out[mode][1]) < 1e-4, mode
+    with pytest.raises(Exception):
+        m.handle.set_option("tg_fuse", 3)
 
 
 @pytest.mark.parametrize("arch", O.ARCHS)

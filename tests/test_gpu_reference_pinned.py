@@ -223,15 +223,27 @@ def test_training_functions_vs_reference_train_IAN():
     # the second update starts from parameters that took one float32 Adam step: measured 4.7e-6 (round 4; round 3 allowed 1e-2)
     assert np.allclose(got[keep], fx["discrim/metrics"][keep], rtol=2e-4, atol=2e-4), (got, fx["discrim/metrics"])
     assert tr.groups["Z"].t == 2 and tr.groups["dec"].t == 1 and tr.groups["enc"].t == 1     # ONE Adam instance for Z (:266-276)
+    # Parameters after the two updates, PER TENSOR against the reference's end point (round-4 verdict item 6; the round-4 bar
+    # was one aggregate, err.mean() < 0.1 * moved.mean(), which a sign error on a minority of tensors would have passed).
+    # Adam's first step is sign-like -- |step| = lr whatever |g| -- so an element lands 2 lr away from the reference exactly
+    # when its gradient's sign differs, i.e. when |g| is below the implementation's error: the mean |after - reference| of a
+    # tensor is 2 lr x (fraction of flipped elements), held to 2 lr x (the tensor's own float32 noise in the reference's graph
+    # + 1e-3).  Z_params take two steps (gen then discrim0's successor): their bound uses the larger of the two recorded noises.
     after = tr.params_numpy()
-    moved, err = [], []
+    moved, per = [], {}
     for key in fx.files:
         if key.startswith("after/"):
             n = key[6:]
-            moved.append(np.abs(fx[key] - np.asarray(P[n], np.float64)).ravel())
-            err.append(np.abs(after[n] - fx[key]).ravel())
-    moved, err = np.concatenate(moved), np.concatenate(err)
-    assert moved.mean() > 0.5 * tr.lr and err.mean() < 0.1 * moved.mean(), (moved.mean(), err.mean())
+            ref = np.asarray(fx[key], np.float64)
+            moved.append(np.abs(ref - np.asarray(P[n], np.float64)).ravel())
+            nz = max([float(fx["%s/noise32/%s" % (tag, n)]) for tag in ("gen", "discrim0") if "%s/noise32/%s" % (tag, n) in fx.files] or [0.0])
+            per[n] = (float(np.abs(after[n] - ref).mean()), 2 * tr.lr * (nz + 1e-3), nz)
+    moved = np.concatenate(moved)
+    bad = sorted(((e / b, e, b, nz, n) for n, (e, b, nz) in per.items() if e > b), reverse=True)
+    _note("post_update_param_err", {"lr": tr.lr, "tensors": len(per), "over_bound": bad,
+                                    "worst_ratio_to_bound": sorted(((e / b, e, nz, n) for n, (e, b, nz) in per.items()), reverse=True)[:8]})
+    assert moved.mean() > 0.5 * tr.lr, moved.mean()
+    assert len(per) >= 60 and not bad, bad[:6]
     untouched = [n for n in fx["untrained"].tolist() if n.startswith("l_IAF")]
     frozen = tr.state_dict()
     assert len(untouched) == 12 and all(np.array_equal(frozen[n], P[n]) for n in untouched)   # MADE is never trained
