@@ -135,6 +135,27 @@ def pmc_traffic(arch, B):
         return None, None
 
 
+def b1_pmc_traffic(which):
+    """HBM bytes per brush event ('edit') / per batch-1 reconstruction ('b1_recon') from the committed rocprofv3 PMC passes of
+    scripts/b1_chain_profile.py (profiles/r*_batch1_chains.json: scripts/profile_b1.sh + scripts/summarize_b1_profile.py); None when
+    absent or taken on other kernel sources than the ones running now (csrc digest)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_batch1_chains.json")))
+    if not files:
+        return None, None
+    try:
+        from neural_photo_editor_amd import build as _b
+        js = json.load(open(files[-1]))
+        src = os.path.relpath(files[-1], ROOT)
+        cur = _b._digest("inference")
+        if js.get("csrc_digest") not in (cur, _b._digest()):
+            return None, "%s is stale (csrc digest %s != current %s)" % (src, str(js.get("csrc_digest"))[:12], cur[:12])
+        v = js.get(which, {}).get("hbm_bytes_per_unit")
+        return (float(v) if v else None), "bytes per %s (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % ("brush event" if which == "edit" else "reconstruction", src)
+    except Exception:
+        return None, None
+
+
 def train_pmc_traffic(batch):
     """HBM bytes per update of the training step from the committed rocprofv3 PMC passes (profiles/r*_train_ian_b128.json, written by
     scripts/profile_train.sh + scripts/summarize_train_profile.py); None when absent, taken at another batch, or taken on other kernel
@@ -549,7 +570,7 @@ def main(argv=None):
                                      "frac_executed": EDIT_STEP_BYTES_EXECUTED / (float(np.percentile(lat5[20:], 50)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      "executed_basis": "151 MB: with the decoder-forward cache an event runs ONE decoder forward (77 MB) + one "
                                                        "backward-data sweep (74 MB); reported beside the 232 MB algorithmic basis",
-                                     "traffic": None,
+                                     "traffic": b1_pmc_traffic("edit")[0], "traffic_unit": b1_pmc_traffic("edit")[1],
                                      "basis": "SURVEY 8(d): 232 MB algorithmic per brush event (2 decoder forwards + 1 backward-data at batch 1, "
                                               "weights uncached) over the p50 of one ian_brush_step call (host copies and the sync included); the "
                                               "event is latency-bound (13-17 dependent launches), not bandwidth-bound"},
@@ -593,7 +614,8 @@ def main(argv=None):
                     lat_api.append((time.perf_counter() - t) * 1e3)
                 ach = B1_RECON_BYTES / (dev_ms * 1e-3) / 1e9
                 b1 = {"device_ms": dev_ms, "api_p50_ms": float(np.percentile(lat_api[20:], 50)), "api_p95_ms": float(np.percentile(lat_api[20:], 95)),
-                      "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                      "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                                   "traffic": b1_pmc_traffic("b1_recon")[0], "traffic_unit": b1_pmc_traffic("b1_recon")[1],
                                    "basis": "SURVEY 8(d): 214 MB per batch-1 reconstruction (encoder 137 MB + decoder 77 MB, the weights), "
                                             "floor 26.9 us at 8 TB/s; device_ms = HIP-event time of %d back-to-back ian_reconstruct calls on "
                                             "device buffers / %d; api = encode_images + sample_at through the API.py surface (host numpy in/out, "

@@ -54,6 +54,21 @@ int ian_layer_backward_data(ian_layer* l, const float* dy, int32_t n, float* dx,
 /* dparams[i] (+)= d loss / d param_i in the reference layout (same order as set_params). */
 int ian_layer_backward_weight(ian_layer* l, const float* x, const float* dy, int32_t n, float* const* dparams,
                               int32_t nparams, int32_t accumulate, void* stream);
+/* Batch statistics in the epilogue of the launch that produces the tensor (round 5).  ian_layer_stats_next arms the layer's NEXT
+   ian_layer_forward / ian_layer_backward_data (/ the data-gradient GEMM of ian_layer_head6_backward) -- one shot -- to write, beside
+   its output, per row tile and channel the float64 partial sums the two-stage statistics of ian_k_colstats start from:
+     mode 1: s1 = sum v, s2 = sum v*v of the stored values v            (ian_k_colstats mode 0: batch-norm forward)
+     mode 2: g = v * act'(a), s1 = sum g, s2 = sum g * (yraw - mean) * inv_std   (mode 1: dbeta, dgamma; a / yraw laid out like the
+             output; yraw NULL: s2 = 0)
+   partial[chunk][2][C] doubles, cap_doubles available.  ian_layer_stats_chunks: number of chunks the last launch wrote -- feed
+   them to ian_k_tree_sum / ian_k_bn_finish / ian_k_bn_bwd_finish as `nchunks` -- or 0 when that launch could not carry them
+   (split-K schedule, VALU kernel, workspace too small -- and ALWAYS in the product library: the statistics epilogue measured
+   4 % slower per training update than the colstats passes it replaces and is compiled into libian_ablation.so only): the caller
+   then runs ian_k_colstats as before.  Chunk boundaries are multiples of the GEMM's row-tile height in (image, pixel) order;
+   sums differ from ian_k_colstats' in summation order only. */
+int ian_layer_stats_next(ian_layer* l, int32_t mode, const float* a, const float* yraw, const float* mean, const float* inv_std,
+                         int32_t act, double* partial, int64_t cap_doubles);
+int32_t ian_layer_stats_chunks(ian_layer* l);
 /* Forward of THREE 2-filter MDCL layers that read the same 128-channel map with the same tap list (the R, G_a, B_a layers
    of the RGB-Beta head, IAN.py:183-199) in one pass over the map: y_k = act_k(x (*) W_k), k = 0..2, each an NHWC map with
    pixel stride y_stride (kernels_head.hip head6_kernel: one dense 128 -> 6*taps contraction per pixel on the matrix
@@ -116,6 +131,13 @@ int ian_k_bn_running(float* run_mean, const float* mean, float* run_inv_std, con
 int ian_k_bn_stats_affine(const float* y, int64_t rows, int32_t C, int32_t stride, double* workspace, int32_t nchunks, double* sums,
                           float count, float eps, const float* gamma, const float* beta, float* mean, float* inv_std, float* scale,
                           float* shift, float* run_mean, float* run_inv_std, float keep, float alpha, void* stream);
+/* second stages alone, for partial sums that are already in `workspace` ([nchunks][2][C] doubles: ian_layer_stats_next): the tree +
+   affine (+ running averages) of ian_k_bn_stats_affine, resp. the tree + dbeta / dgamma accumulation of ian_k_bn_bwd_stats */
+int ian_k_bn_finish(const double* workspace, int32_t nchunks, int32_t C, double* sums, float count, float eps, const float* gamma,
+                    const float* beta, float* mean, float* inv_std, float* scale, float* shift, float* run_mean, float* run_inv_std,
+                    float keep, float alpha, void* stream);
+int ian_k_bn_bwd_finish(const double* workspace, int32_t nchunks, int32_t C, double* sums, float* gbeta, int32_t acc_beta, float* ggamma,
+                        int32_t acc_gamma, void* stream);
 int ian_k_bn_bwd_stats(const float* dA, const float* a, const float* y, const float* mean, const float* inv_std, int64_t rows, int32_t C,
                        int32_t stride, int32_t act, double* workspace, int32_t nchunks, double* sums, float* gbeta, int32_t acc_beta,
                        float* ggamma, int32_t acc_gamma, void* stream);

@@ -35,6 +35,23 @@ struct TgTile {  // reduce pass: one output tile
 
 enum { TG_EPI_FWD = 0, TG_EPI_BWD = 1 };
 
+// Batch statistics computed in the epilogue of the launch that PRODUCES the tensor (round 5: the training step's colstats passes
+// re-read every normalised tensor -- 5 GB per update).  Per output row tile and channel, float64 partial sums over the tile's rows:
+//   mode 1 (forward, Lasagne batch_norm statistics): s1 = sum v, s2 = sum v*v of the stored value v, every element widened first;
+//   mode 2 (backward: dbeta, dgamma): g = v * act'(a), s1 = sum g, s2 = sum g * xhat, xhat = (yraw - mean) * inv_std -- float32
+//           products, four rows added in float32, the rest in float64 (the arithmetic of colstats_kernel, kernels_train.hip).
+// partial[chunk][2][C] doubles, chunk = (row tile index) * ncls + class: the second stage (tree over chunks) is unchanged, and
+// the chunk boundaries (multiples of the tile height within the (image, pixel) row order) do not depend on the batch.
+// Only launches whose tiles are not split over K carry it (the host falls back to colstats otherwise).
+struct TgStats {
+  double* partial = nullptr;
+  const float* a = nullptr;       // mode 2: post-activation forward value (for act')
+  const float* yraw = nullptr;    // mode 2: pre-normalisation value
+  const float* mean = nullptr;
+  const float* inv_std = nullptr;
+  int mode = 0, act = 0, C = 0, ncls = 1;
+};
+
 struct TgEpilogue {
   const float* scale;  // per output channel (folded BN gamma*inv_std) or nullptr (=1)
   const float* shift;  // per output channel (folded beta/bias) or nullptr (=0)
@@ -45,6 +62,7 @@ struct TgEpilogue {
                        // batch-norm of a dense layer whose output is viewed as an NHWC map (IAN_simple.py:129-139)
   int mode;            // TG_EPI_FWD: y = act((acc+res)*scale+shift)
                        // TG_EPI_BWD: y = (acc [+res]) * act'(yfwd) * scale   (gradient wrt pre-affine value)
+  TgStats st;          // statistics of the stored values (training step), or mode 0
 };
 
 struct TgParams {
@@ -104,6 +122,20 @@ static inline TgShape tg_shape(int cfg) {
 // batch-1 chains use.  The large tiles are compiled WITHOUT that epilogue (it cost the 256x128 tile 95 spilled VGPRs).
 static inline bool tg_fuse_supported(int cfg) {
   return cfg == TG_32x128 || cfg == TG_64x64 || cfg == TG_128x64 || cfg == TG_128x32;
+}
+
+// launches that can carry the GEMM-epilogue batch statistics (TgStats): a separate kernel instantiation exists for the
+// register-staged K-loop schedules 1 / 2 of every tile up to 128 x 128
+// -- in libian_ablation.so.  The product library carries none of them (measured: the training update got 4 % SLOWER; the colstats
+// passes this replaces are HBM-bound and already run under the weight-gradient GEMMs of the second stream, the epilogue version
+// puts the same bytes on the MFMA-bound kernel's critical path): there every request is answered with 0 chunks.
+static inline bool tg_stats_supported(int cfg, int variant) {
+#ifdef IAN_ABLATION
+  return cfg != TG_256x128 && (variant == 1 || variant == 2);
+#else
+  (void)cfg; (void)variant;
+  return false;
+#endif
 }
 
 // one-image form of the 5x5/s2 transposed conv and of its backward-data (kernels_b1.hip): whole contraction per
@@ -349,6 +381,12 @@ hipError_t launch_bn_stats_affine(const ColStatsArgs& a, int nchunks, double* su
                                   float* run_inv_std, float keep, float alpha, hipStream_t s);
 hipError_t launch_bn_bwd_stats(const ColStatsArgs& a, int nchunks, double* sums, float* gbeta, int acc_beta, float* ggamma,
                                int acc_gamma, hipStream_t s);
+// the second stages alone (partials already in place: GEMM-epilogue statistics, TgStats)
+hipError_t launch_bn_finish(const double* partial, int nchunks, int C, double* sums, float count, float eps, const float* gamma,
+                            const float* beta, float* mean, float* inv_std, float* scale, float* shift, float* run_mean,
+                            float* run_inv_std, float keep, float alpha, hipStream_t s);
+hipError_t launch_bn_bwd_finish(const double* partial, int nchunks, int C, double* sums, float* gbeta, int acc_beta, float* ggamma,
+                                int acc_gamma, hipStream_t s);
 // out[i] = pairwise tree over k < count of partial[k*width + i] (fixed order: see kernels_train.hip)
 hipError_t launch_tree_sum(const double* partial, int count, int width, double* out, hipStream_t s);
 hipError_t launch_bn_make_affine(const double* sums, float count, float eps, const float* gamma, const float* beta,

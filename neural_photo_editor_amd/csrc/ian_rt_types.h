@@ -208,6 +208,12 @@ struct ian_handle {
   // available, the graphs keep their copy nodes).  Every hipMemcpyAsync of a graph is a 4.6 us copy kernel plus a kernel
   // boundary on this runtime: four of them per brush event.
   float* pin_dev = nullptr;
+  // training step (ian_layer_stats_next): the NEXT tap-GEMM launch through this context also produces the batch statistics of
+  // the tensor it stores (TgStats); one-shot.  stats_chunks_last = partial rows the last launch wrote (0: it could not -- split-K
+  // schedule, VALU path, workspace too small -- and the caller runs colstats instead)
+  TgStats stats_next;
+  long long stats_cap = 0;       // doubles available at stats_next.partial
+  int stats_chunks_last = 0;
   float* out_mirror = nullptr;   // set around run_segment(DEC): the batch-1 image kernel also writes the image there
   // set around run_decoder_backward by ian_brush_step: the latent's backward GEMV also applies Z += coef * (dZ * gscale) (one launch
   // less per brush event); done = the fused form was taken (else the caller launches latent_update_kernel)

@@ -73,6 +73,21 @@ int ian_k_bn_stats_affine(const float* y, int64_t rows, int32_t C, int32_t strid
              "ian_k_bn_stats_affine");
 }
 
+int ian_k_bn_finish(const double* workspace, int32_t nchunks, int32_t C, double* sums, float count, float eps, const float* gamma,
+                    const float* beta, float* mean, float* inv_std, float* scale, float* shift, float* run_mean, float* run_inv_std,
+                    float keep, float alpha, void* stream) {
+  if (!workspace || !sums || !gamma || !beta || !mean || !inv_std || !scale || !shift || C <= 0 || nchunks <= 0 || count <= 0 ||
+      (!run_mean) != (!run_inv_std))
+    return bad("ian_k_bn_finish");
+  return chk(launch_bn_finish(workspace, nchunks, C, sums, count, eps, gamma, beta, mean, inv_std, scale, shift, run_mean, run_inv_std, keep,
+                              alpha, ST), "ian_k_bn_finish");
+}
+int ian_k_bn_bwd_finish(const double* workspace, int32_t nchunks, int32_t C, double* sums, float* gbeta, int32_t acc_beta, float* ggamma,
+                        int32_t acc_gamma, void* stream) {
+  if (!workspace || !sums || C <= 0 || nchunks <= 0 || (!gbeta) != (!ggamma)) return bad("ian_k_bn_bwd_finish");
+  return chk(launch_bn_bwd_finish(workspace, nchunks, C, sums, gbeta, acc_beta, ggamma, acc_gamma, ST), "ian_k_bn_bwd_finish");
+}
+
 int ian_k_bn_bwd_stats(const float* dA, const float* a, const float* y, const float* mean, const float* inv_std, int64_t rows, int32_t C,
                        int32_t stride, int32_t act, double* workspace, int32_t nchunks, double* sums, float* gbeta, int32_t acc_beta,
                        float* ggamma, int32_t acc_gamma, void* stream) {

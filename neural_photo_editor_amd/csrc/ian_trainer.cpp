@@ -135,6 +135,13 @@ struct ian_trainer {
   const float* X = nullptr;
   const float* eps = nullptr;
   int head6 = 1, update_running = 1;
+  // batch statistics in the epilogue of the GEMM that produces the normalised tensor (ian_layer_stats_next) instead of a colstats
+  // pass that re-reads it; single-process step only: the data-parallel `exact` step keeps the per-image chunks of ian_k_colstats,
+  // whose partition does not depend on the tile shape the autotuner picks per batch size (bitwise rank-order invariance).
+  // OFF, and effective in libian_ablation.so only (the product's GEMMs answer every request with 0 chunks): measured on MI355X at
+  // 128 images, in-process A/B, 103.9 vs 99.7 ms per G+D pair -- the colstats passes are HBM-bound kernels that already run under
+  // the weight-gradient GEMMs of the second stream; folded into the epilogue the same bytes sit on the MFMA-bound critical path
+  int fused_stats = 0;
   hipStream_t st = nullptr;
   // weight-gradient GEMMs (ian_layer_backward_weight: 19 % of the step) are off the critical path -- nothing reads a gradient
   // before the regularisers -- so they are issued on a second stream behind an event on the compute stream (their dy operand
@@ -666,6 +673,20 @@ int acc64(ian_trainer* t, const std::string& pname, const double* src, int64_t c
   TK(ian_k_axpy_f64(alpha, src, G(t, pname), count, t->touched.count(pname) ? 1 : 0, t->st));
   return mark(t, {pname});
 }
+// ---- GEMM-epilogue statistics (include/ian_train.h ian_layer_stats_next) ------------------------------------------------
+bool fuse_stats(const ian_trainer* t) { return t->fused_stats && !t->exact; }
+int arm_fwd_stats(ian_trainer* t, const std::string& lname) {      // the layer's next forward also sums v, v*v per row tile
+  if (!fuse_stats(t)) return 0;
+  TL(lay(t, lname), ian_layer_stats_next(lay(t, lname), 1, nullptr, nullptr, nullptr, nullptr, 0, t->ws_stats, (int64_t)t->ws_stats_cap));
+  return 0;
+}
+int arm_bwd_stats(ian_trainer* t, const std::string& lname, const BN& bn, const float* a, const float* yraw, int act) {
+  if (!fuse_stats(t)) return 0;   // the layer's next backward-data also sums g = dA act'(a) and g xhat of the gradient it stores
+  TL(lay(t, lname), ian_layer_stats_next(lay(t, lname), 2, a, yraw, bn.mean, bn.inv_std, act, t->ws_stats, (int64_t)t->ws_stats_cap));
+  return 0;
+}
+int armed_chunks(ian_trainer* t, const std::string& lname) { return fuse_stats(t) ? ian_layer_stats_chunks(lay(t, lname)) : 0; }
+
 // exact mode, after the per-rank sums have been combined over the ranks: affine, apply, running averages (same running_math as the
 // fused single-process second stage: data-parallel checkpoints carry bit-identical running averages)
 int bn_forward_finish(ian_trainer* t, BN& bn, const float* y, float* a, int64_t rows, int C, int stride, const float* gamma, const float* beta,
@@ -676,11 +697,12 @@ int bn_forward_finish(ian_trainer* t, BN& bn, const float* y, float* a, int64_t 
   if (rm) TK(ian_k_bn_running(rm, bn.mean, ri, bn.inv_std, C, 0.9f, 0.1f, t->st));
   return 0;
 }
+// pre > 0: the producing GEMM already left `pre` chunk partials in the statistics workspace (arm_fwd_stats)
 int bn_forward(ian_trainer* t, BN& bn, const float* y, float* a, int64_t rows, int C, int stride, const float* gamma, const float* beta, int act,
-               int64_t count_rows, const char* running) {
-  double* ws;
+               int64_t count_rows, const char* running, int pre = 0) {
+  double* ws = t->ws_stats;
   int rc;
-  if ((rc = ws_for(t, rows, C, &ws))) return rc;
+  if (pre <= 0 && (rc = ws_for(t, rows, C, &ws))) return rc;   // (pre > 0: the partials are already in the workspace -- it must not move)
   float *rm = nullptr, *ri = nullptr;
   if (running && t->update_running) {  // r = (1 - alpha) r + alpha * batch   (Lasagne BatchNormLayer alpha = 0.1)
     rm = P(t, std::string(running) + ".mean");
@@ -688,8 +710,11 @@ int bn_forward(ian_trainer* t, BN& bn, const float* y, float* a, int64_t rows, i
   }
   if (!t->exact) {  // no collective between the two stages: one fused second stage
     bn.count = (float)count_rows;
-    TK(ian_k_bn_stats_affine(y, rows, C, stride, ws, chunks(t, rows), bn.sums, bn.count, BN_EPS, gamma, beta, bn.mean, bn.inv_std, bn.scale,
-                             bn.shift, rm, ri, 0.9f, 0.1f, t->st));
+    if (pre > 0)
+      TK(ian_k_bn_finish(t->ws_stats, pre, C, bn.sums, bn.count, BN_EPS, gamma, beta, bn.mean, bn.inv_std, bn.scale, bn.shift, rm, ri, 0.9f, 0.1f, t->st));
+    else
+      TK(ian_k_bn_stats_affine(y, rows, C, stride, ws, chunks(t, rows), bn.sums, bn.count, BN_EPS, gamma, beta, bn.mean, bn.inv_std, bn.scale,
+                               bn.shift, rm, ri, 0.9f, 0.1f, t->st));
     TK(ian_k_affine(y, a, bn.scale, bn.shift, rows, C, stride, act, t->st));
     return 0;
   }
@@ -700,10 +725,10 @@ int bn_forward(ian_trainer* t, BN& bn, const float* y, float* a, int64_t rows, i
 int bn_backward_finish(ian_trainer* t, BN& bn, const float* dA, const float* a, const float* y, float* dy, int64_t rows, int C, int stride, int act,
                        const std::string& gname, const std::string& bname, bool want_w);
 int bn_backward(ian_trainer* t, BN& bn, const float* dA, const float* a, const float* y, float* dy, int64_t rows, int C, int stride, int act,
-                const std::string& gname, const std::string& bname, bool want_w) {
-  double* ws;
+                const std::string& gname, const std::string& bname, bool want_w, int pre = 0) {
+  double* ws = t->ws_stats;
   int rc;
-  if ((rc = ws_for(t, rows, C, &ws))) return rc;
+  if (pre <= 0 && (rc = ws_for(t, rows, C, &ws))) return rc;
   if (!t->exact) {
     float *gb = nullptr, *gg = nullptr;
     int ab = 0, ag = 0;
@@ -711,7 +736,8 @@ int bn_backward(ian_trainer* t, BN& bn, const float* dA, const float* a, const f
       gb = G(t, bname); gg = G(t, gname);
       ab = t->touched.count(bname) ? 1 : 0; ag = t->touched.count(gname) ? 1 : 0;
     }
-    TK(ian_k_bn_bwd_stats(dA, a, y, bn.mean, bn.inv_std, rows, C, stride, act, ws, chunks(t, rows), bn.bsums, gb, ab, gg, ag, t->st));
+    if (pre > 0) TK(ian_k_bn_bwd_finish(t->ws_stats, pre, C, bn.bsums, gb, ab, gg, ag, t->st));   // partials from the GEMM that stored dA
+    else TK(ian_k_bn_bwd_stats(dA, a, y, bn.mean, bn.inv_std, rows, C, stride, act, ws, chunks(t, rows), bn.bsums, gb, ab, gg, ag, t->st));
     if (want_w && (rc = mark(t, {bname, gname}))) return rc;
     TK(ian_k_bn_bwd(dA, a, y, bn.mean, bn.inv_std, bn.scale, bn.bsums, bn.count, dy, rows, C, stride, act, t->st));
     return 0;
@@ -764,7 +790,9 @@ int wgrad(ian_trainer* t, const std::string& lname, const float* x, const float*
   TL(r.l, ian_layer_backward_weight(r.l, x, dy, t->n, g.data(), (int)g.size(), t->touched.count(r.pnames[0]) ? 1 : 0, ws));
   return mark(t, r.pnames);
 }
-int head_backward(ian_trainer* t, const float* x, const float* dR, const float* dG, const float* dB, float* dx, bool want_w) {
+int head_backward(ian_trainer* t, const float* x, const float* dR, const float* dG, const float* dB, float* dx, bool want_w,
+                  const BN* arm = nullptr, const float* arm_a = nullptr, const float* arm_y = nullptr, int* pre = nullptr) {
+  if (pre) *pre = 0;
   const char* names[3] = {"R", "G_a", "B_a"};
   const float* dys[3] = {dR, dG, dB};
   bool accs[3];
@@ -773,10 +801,15 @@ int head_backward(ian_trainer* t, const float* x, const float* dR, const float* 
     std::vector<float*> g[3];
     for (int i = 0; i < 3; ++i)
       for (auto& p : t->layers.at(names[i]).pnames) g[i].push_back(G(t, p));
+    if (arm && fuse_stats(t)) {   // bnorm_dc4's backward statistics ride on the GEMM that stores dh4
+      const int arc = arm_bwd_stats(t, "R", *arm, arm_a, arm_y, IAN_ACT_LRELU);
+      if (arc) return arc;
+    }
     const int rc = ian_layer_head6_backward(lay(t, "R"), lay(t, "G_a"), lay(t, "B_a"), x, dR, dG, dB, t->n, 32, dx, 128, 0,
                                             want_w ? g[0].data() : nullptr, want_w ? g[1].data() : nullptr, want_w ? g[2].data() : nullptr,
                                             want_w ? (int)g[0].size() : 0, accs[0] ? 1 : 0, t->st);
     if (rc == 0) {
+      if (pre) *pre = armed_chunks(t, "R");
       if (want_w)
         for (int i = 0; i < 3; ++i) {
           const int mrc = mark(t, t->layers.at(names[i]).pnames);
@@ -784,6 +817,7 @@ int head_backward(ian_trainer* t, const float* x, const float* dR, const float* 
         }
       return 0;
     }
+    (void)ian_layer_stats_next(lay(t, "R"), 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0);   // the per-layer fallback accumulates dx in three launches
     if (rc != -4) return tfail(t, rc, "ian_layer_head6_backward failed (%d): %s", rc, ian_layer_last_error(lay(t, "R")));
   }
   for (int i = 0; i < 3; ++i) {
@@ -803,9 +837,10 @@ int enc_forward(ian_trainer* t, Bufs& E, std::map<std::string, BN>& bn, const fl
   for (int i = 2; i <= 4; ++i) {
     const int w = ENC_WIDTHS[i - 1], hw = 64 >> i;
     const std::string s = std::to_string(i), sp = std::to_string(i - 1), bnn = "bnorm" + s;
+    if ((rc = arm_fwd_stats(t, "enc_conv" + s))) return rc;
     TL(lay(t, "enc_conv" + s), ian_layer_forward(lay(t, "enc_conv" + s), E["a" + sp], n, E["y" + s], 0, nullptr, nullptr, 0, t->st));
     if ((rc = bn_forward(t, bn["bn" + s], E["y" + s], E["a" + s], (int64_t)n * hw * hw, w, w, P(t, bnn + ".gamma"), P(t, bnn + ".beta"),
-                         IAN_ACT_LRELU, (int64_t)n * hw * hw, running ? bnn.c_str() : nullptr)))
+                         IAN_ACT_LRELU, (int64_t)n * hw * hw, running ? bnn.c_str() : nullptr, armed_chunks(t, "enc_conv" + s))))
       return rc;
   }
   TK(ian_k_globalpool(E["a4"], E["feat"], n, 16, 1024, 1024, 1024, t->st));
@@ -853,14 +888,19 @@ int enc_backward(ian_trainer* t, Bufs& E, std::map<std::string, BN>& bn, int t0,
     if ((rc = mark(t, {"minibatch_discrim.theta", "minibatch_discrim.log_weight_scale"}))) return rc;
   }
   TK(ian_k_globalpool_bwd(E["dfeat"], E["da4"], n, 16, 1024, 1024, 1024, feature_seeded ? 1 : 0, t->st));
+  int pre_next = 0;   // chunk partials the previous backward-data GEMM left for the next batch-norm backward (0: run colstats)
   for (int i = 4; i >= 2; --i) {
     const int w = ENC_WIDTHS[i - 1], hw = 64 >> i;
     const std::string s = std::to_string(i), sp = std::to_string(i - 1);
     float *da = E["da" + s], *a = E["a" + s], *y = E["y" + s];
-    if ((rc = bn_backward(t, bn["bn" + s], da, a, y, da, (int64_t)n * hw * hw, w, w, IAN_ACT_LRELU, "bnorm" + s + ".gamma", "bnorm" + s + ".beta", want_w)))
+    if ((rc = bn_backward(t, bn["bn" + s], da, a, y, da, (int64_t)n * hw * hw, w, w, IAN_ACT_LRELU, "bnorm" + s + ".gamma", "bnorm" + s + ".beta", want_w,
+                          pre_next)))
       return rc;
     if (want_w && (rc = wgrad(t, "enc_conv" + s, E["a" + sp], da))) return rc;
+    // the gradient this launch stores is the input of the next normalisation down (bnorm<i-1>): its statistics ride along
+    if (i - 1 >= 2 && (rc = arm_bwd_stats(t, "enc_conv" + s, bn["bn" + sp], E["a" + sp], E["y" + sp], IAN_ACT_LRELU))) return rc;
     TL(lay(t, "enc_conv" + s), ian_layer_backward_data(lay(t, "enc_conv" + s), da, n, E["da" + sp], 0, feature_seeded ? 1 : 0, t->st));
+    pre_next = i - 1 >= 2 ? armed_chunks(t, "enc_conv" + s) : 0;
   }
   // enc_conv1: bias + lrelu, no batch-norm (IAN.py:71-80)
   if (want_w) {
@@ -956,24 +996,28 @@ int dec_forward(ian_trainer* t, Bufs& D, std::map<std::string, BN>& bn, const fl
     const int64_t rows = (int64_t)n * (2 * s.hw) * (2 * s.hw);
     auto g = [&](int j, const char* w) { return P(t, blk + "bnorm" + std::to_string(j) + "." + w); };
     auto rn = [&](int j) -> std::string { return blk + "bnorm" + std::to_string(j); };
+    if ((rc = arm_fwd_stats(t, s.dc))) return rc;
     TL(lay(t, s.dc), ian_layer_forward(lay(t, s.dc), h, n, D[blk + "_x"], 0, nullptr, nullptr, 0, t->st));
     if ((rc = bn_forward(t, bn[blk + "_bn0"], D[blk + "_x"], D[blk + "_a"], rows, s.co, s.co, g(0, "gamma"), g(0, "beta"), IAN_ACT_LRELU, rows,
-                         running ? rn(0).c_str() : nullptr)))
+                         running ? rn(0).c_str() : nullptr, armed_chunks(t, s.dc))))
       return rc;
+    if ((rc = arm_fwd_stats(t, blk))) return rc;
     TL(lay(t, blk), ian_layer_forward(lay(t, blk), D[blk + "_a"], n, D[blk + "_b"], 0, nullptr, nullptr, 0, t->st));
     if ((rc = bn_forward(t, bn[blk + "_bn1"], D[blk + "_b"], D[blk + "_c"], rows, s.co, s.co, g(1, "gamma"), g(1, "beta"), IAN_ACT_LRELU, rows,
-                         running ? rn(1).c_str() : nullptr)))
+                         running ? rn(1).c_str() : nullptr, armed_chunks(t, blk))))
       return rc;
+    if ((rc = arm_fwd_stats(t, blk + "2"))) return rc;
     TL(lay(t, blk + "2"), ian_layer_forward(lay(t, blk + "2"), D[blk + "_c"], n, D[blk + "_e"], 0, nullptr, D[blk + "_x"], 0, t->st));  // ElemwiseSum (layers.py:415)
     if ((rc = bn_forward(t, bn[blk + "_bn2"], D[blk + "_e"], D[blk + "_h"], rows, s.co, s.co, g(2, "gamma"), g(2, "beta"), IAN_ACT_LRELU, rows,
-                         running ? rn(2).c_str() : nullptr)))
+                         running ? rn(2).c_str() : nullptr, armed_chunks(t, blk + "2"))))
       return rc;
     h = D[blk + "_h"];
   }
   const int64_t rows = (int64_t)n * 4096;
+  if ((rc = arm_fwd_stats(t, "dec_conv4"))) return rc;
   TL(lay(t, "dec_conv4"), ian_layer_forward(lay(t, "dec_conv4"), h, n, D["y4"], 0, nullptr, nullptr, 0, t->st));
   if ((rc = bn_forward(t, bn["bn4"], D["y4"], D["h4"], rows, 128, 128, P(t, "bnorm_dc4.gamma"), P(t, "bnorm_dc4.beta"), IAN_ACT_LRELU, rows,
-                       running ? "bnorm_dc4" : nullptr)))
+                       running ? "bnorm_dc4" : nullptr, armed_chunks(t, "dec_conv4"))))
     return rc;
   const int sg = IAN_ACT_SIGMOID;
   // R = sigmoid(MDCL(h4)), G_a, B_a (IAN.py:183-199): the three layers that read the 128-channel map, one pass over it
@@ -1009,14 +1053,18 @@ int dec_backward(ian_trainer* t, Bufs& D, std::map<std::string, BN>& bn, const f
   TL(lay(t, "G_b"), ian_layer_backward_data(lay(t, "G_b"), D["gG"], n, D["dRt"], 0, 0, t->st));
   TK(ian_k_grad_pass(D["dRt"], 32, 0, D["gR"], D["R"], 32, rows, 2, sg, 1, t->st));
   // R = sigmoid(R(h4)): all three seeds are final here
-  if ((rc = head_backward(t, D["h4"], D["gR"], D["gG"], D["gB"], D["dh4"], want_w))) return rc;
+  int pre = 0;   // chunk partials the GEMM that stored a gradient left for the batch-norm backward that consumes it (0: colstats)
+  if ((rc = head_backward(t, D["h4"], D["gR"], D["gG"], D["gB"], D["dh4"], want_w, &bn["bn4"], D["h4"], D["y4"], &pre))) return rc;
   // dec_conv4 + bnorm_dc4 + lrelu
-  if ((rc = bn_backward(t, bn["bn4"], D["dh4"], D["h4"], D["y4"], D["dh4"], rows, 128, 128, IAN_ACT_LRELU, "bnorm_dc4.gamma", "bnorm_dc4.beta", want_w)))
+  if ((rc = bn_backward(t, bn["bn4"], D["dh4"], D["h4"], D["y4"], D["dh4"], rows, 128, 128, IAN_ACT_LRELU, "bnorm_dc4.gamma", "bnorm_dc4.beta", want_w,
+                        pre)))
     return rc;
   const auto& ST = dec_stages();
   const std::string last_blk = ST.back().blk;
   if (want_w && (rc = wgrad(t, "dec_conv4", D[last_blk + "_h"], D["dh4"]))) return rc;
+  if ((rc = arm_bwd_stats(t, "dec_conv4", bn[last_blk + "_bn2"], D[last_blk + "_h"], D[last_blk + "_e"], IAN_ACT_LRELU))) return rc;
   TL(lay(t, "dec_conv4"), ian_layer_backward_data(lay(t, "dec_conv4"), D["dh4"], n, D[last_blk + "_dh"], 0, 0, t->st));
+  pre = armed_chunks(t, "dec_conv4");
   for (int si = (int)ST.size() - 1; si >= 0; --si) {
     const DecStage& s = ST[si];
     const std::string blk = s.blk;
@@ -1024,20 +1072,31 @@ int dec_backward(ian_trainer* t, Bufs& D, std::map<std::string, BN>& bn, const f
     auto bnn = [&](int j, const char* w) { return blk + "bnorm" + std::to_string(j) + "." + w; };
     float *dh = D[blk + "_dh"], *dx = D[blk + "_dx"], *da = D[blk + "_da"], *dcg = D[blk + "_dc"];
     // h = lrelu(bn2(x + d)),  d = MDCL2(c)
-    if ((rc = bn_backward(t, bn[blk + "_bn2"], dh, D[blk + "_h"], D[blk + "_e"], dh, r, s.co, s.co, IAN_ACT_LRELU, bnn(2, "gamma"), bnn(2, "beta"), want_w)))
+    if ((rc = bn_backward(t, bn[blk + "_bn2"], dh, D[blk + "_h"], D[blk + "_e"], dh, r, s.co, s.co, IAN_ACT_LRELU, bnn(2, "gamma"), bnn(2, "beta"), want_w,
+                          pre)))
       return rc;
     if (want_w && (rc = wgrad(t, blk + "2", D[blk + "_c"], dh))) return rc;
+    if ((rc = arm_bwd_stats(t, blk + "2", bn[blk + "_bn1"], D[blk + "_c"], D[blk + "_b"], IAN_ACT_LRELU))) return rc;
     TL(lay(t, blk + "2"), ian_layer_backward_data(lay(t, blk + "2"), dh, n, dcg, 0, 0, t->st));
-    if ((rc = bn_backward(t, bn[blk + "_bn1"], dcg, D[blk + "_c"], D[blk + "_b"], dcg, r, s.co, s.co, IAN_ACT_LRELU, bnn(1, "gamma"), bnn(1, "beta"), want_w)))
+    if ((rc = bn_backward(t, bn[blk + "_bn1"], dcg, D[blk + "_c"], D[blk + "_b"], dcg, r, s.co, s.co, IAN_ACT_LRELU, bnn(1, "gamma"), bnn(1, "beta"), want_w,
+                          armed_chunks(t, blk + "2"))))
       return rc;
     if (want_w && (rc = wgrad(t, blk, D[blk + "_a"], dcg))) return rc;
+    if ((rc = arm_bwd_stats(t, blk, bn[blk + "_bn0"], D[blk + "_a"], D[blk + "_x"], IAN_ACT_LRELU))) return rc;
     TL(lay(t, blk), ian_layer_backward_data(lay(t, blk), dcg, n, da, 0, 0, t->st));
-    if ((rc = bn_backward(t, bn[blk + "_bn0"], da, D[blk + "_a"], D[blk + "_x"], dx, r, s.co, s.co, IAN_ACT_LRELU, bnn(0, "gamma"), bnn(0, "beta"), want_w)))
+    if ((rc = bn_backward(t, bn[blk + "_bn0"], da, D[blk + "_a"], D[blk + "_x"], dx, r, s.co, s.co, IAN_ACT_LRELU, bnn(0, "gamma"), bnn(0, "beta"), want_w,
+                          armed_chunks(t, blk))))
       return rc;
     TK(ian_k_axpy(1.f, dh, dx, r * s.co, 1, t->st));  // residual edge: dx += d(x+d)
     const float* src = si == 0 ? D["h0"] : D[std::string(ST[si - 1].blk) + "_h"];
     if (want_w && (rc = wgrad(t, s.dc, src, dx))) return rc;
+    pre = 0;
+    if (si > 0) {   // the gradient this launch stores enters the previous stage's bnorm2 backward
+      const std::string pb = ST[si - 1].blk;
+      if ((rc = arm_bwd_stats(t, s.dc, bn[pb + "_bn2"], D[pb + "_h"], D[pb + "_e"], IAN_ACT_LRELU))) return rc;
+    }
     TL(lay(t, s.dc), ian_layer_backward_data(lay(t, s.dc), dx, n, si == 0 ? D["dh0"] : D[std::string(ST[si - 1].blk) + "_dh"], 0, 0, t->st));
+    if (si > 0) pre = armed_chunks(t, s.dc);
   }
   // l_dec_fc2: bias + lrelu
   TK(ian_k_bn_bwd(D["dh0"], D["h0"], nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, D["dh0"], n, 8192, 8192, IAN_ACT_LRELU, t->st));
@@ -1617,6 +1676,7 @@ int ian_trainer_set_option(ian_trainer* t, const char* key, double value) {
   else if (k == "head6") t->head6 = value != 0.0;
   else if (k == "overlap_wgrad") t->overlap_wgrad = value != 0.0;
   else if (k == "update_running") t->update_running = value != 0.0;
+  else if (k == "fused_stats") t->fused_stats = value != 0.0;                 // GEMM-epilogue batch statistics (single-process step)
   else if (k == "overlap") t->overlap = value != 0.0;                       // gradient buckets handed over during backward
   else if (k == "bucket_bytes") { t->bucket_bytes = (int64_t)value > 4 ? (int64_t)value : 4; t->plans.clear(); }
   else if (k == "measure_exposed") {

@@ -197,6 +197,117 @@ __device__ __forceinline__ void tg_store(const TgParams& p, const TgItem& it, co
     }
 }
 
+// tg_store + the batch statistics of the stored values (TgStats, ian_internal.h): the same stores, plus per lane and column the
+// float64 sums over this lane's rows, then lanes l / l + 32 (the two row halves of a 32 x 32 block) and the WM row waves of the
+// tile meet in LDS in a fixed order (wm ascending, half 0 then 1) and one thread per column writes the tile's partial.
+// red: the LDS tiles of the K loop, dead by now (the caller has synchronised).
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void tg_store_stats(const TgParams& p, const TgItem& it, const TgClass& cl,
+                                               f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wm, int wn, int lane, double* red) {
+  constexpr int FM = BM / WM / 32, FN = BN / WN / 32, NW = WM * WN, CW = BN / WN;   // CW: columns of one wave
+  const TgStats& st = p.epi.st;
+  const int qhw_mask = (1 << p.qhw_shift) - 1, qw_mask = (1 << p.qw_shift) - 1;
+  const int col_l = lane & 31, half = lane >> 5;
+  const int rhalf = 4 * half;
+  double d1[FN], d2[FN];
+  float fmean[FN], fistd[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    d1[j] = 0.0; d2[j] = 0.0;
+    const int c = it.n0 + wn * CW + j * 32 + col_l;
+    fmean[j] = (st.mode == 2 && st.mean && c < p.Cout) ? st.mean[c] : 0.f;
+    fistd[j] = (st.mode == 2 && st.inv_std && c < p.Cout) ? st.inv_std[c] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    // pass 1: the 16 rows' addresses and, mode 2, their a / yraw operands -- branch-free (a masked element reads offset 0), so
+    // that all 32 x FN loads are in flight together; loaded next to their use they were a chain of 32 exposed latencies per
+    // lane and the fused step measured 1.5 % SLOWER than the colstats passes it replaces
+    size_t yo[16];
+    bool ok[16];
+    float av[16][FN], yv[16][FN];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+      const int m = it.m0 + row;
+      ok[r] = m < p.M;
+      const int n = m >> p.qhw_shift;
+      const int rem = m & qhw_mask;
+      const int oy = (rem >> p.qw_shift) * p.so + cl.py, ox = (rem & qw_mask) * p.so + cl.px;
+      yo[r] = ok[r] ? (((size_t)n * p.OH + oy) * p.OW + ox) * p.y_stride : 0;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int c = it.n0 + wn * CW + j * 32 + col_l;
+        const size_t o = (ok[r] && c < p.Cout) ? yo[r] + c : 0;
+        av[r][j] = (st.mode == 2 && st.act) ? st.a[o] : 0.f;
+        yv[r][j] = (st.mode == 2 && st.yraw) ? st.yraw[o] : 0.f;
+      }
+    }
+    // pass 2: epilogue values, stores, sums
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      float g[FN][4], t[FN][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * rq + e;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int c = it.n0 + wn * CW + j * 32 + col_l;
+          float gv = 0.f, tv = 0.f;
+          if (ok[r] && c < p.Cout) {
+            const size_t yoff = yo[r] + c;
+            const float v = epilogue_value(p.epi, acc[i][j][r], yoff, c);
+            p.y[yoff] = v;
+            if (st.mode == 1) {
+              d1[j] += (double)v;
+              d2[j] += (double)v * (double)v;            // exact product, float64 accumulation (colstats mode 0)
+            } else {
+              gv = st.act ? v * act_grad_rt(av[r][j], st.act) : v;
+              if (st.yraw) tv = gv * ((yv[r][j] - fmean[j]) * fistd[j]);
+            }
+          }
+          g[j][e] = gv; t[j][e] = tv;
+        }
+      }
+      if (st.mode == 2) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {   // four rows in float32, (0+1)+(2+3), everything longer in float64 (colstats modes 1, 2)
+          d1[j] += (double)((g[j][0] + g[j][1]) + (g[j][2] + g[j][3]));
+          d2[j] += (double)((t[j][0] + t[j][1]) + (t[j][2] + t[j][3]));
+        }
+      }
+    }
+  }
+  const int wave = wm * WN + wn;
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    double* q = red + ((size_t)(wave * 2 + half) * CW + j * 32 + col_l) * 2;
+    q[0] = d1[j];
+    q[1] = d2[j];
+  }
+  __syncthreads();
+  const int tid = wave * 64 + lane;
+  if (tid < BN) {
+    const int w2 = tid / CW, cc = tid % CW;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int m2 = 0; m2 < WM; ++m2)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const double* q = red + ((size_t)((m2 * WN + w2) * 2 + h2) * CW + cc) * 2;
+        s1 += q[0];
+        s2 += q[1];
+      }
+    const int c = it.n0 + tid;
+    if (c < st.C) {
+      double* o = st.partial + ((size_t)(it.m0 / BM) * st.ncls + it.cls) * 2 * st.C;
+      o[c] = s1;
+      o[st.C + c] = s2;
+    }
+  }
+  (void)NW;
+}
+
 // VAR selects the K-loop schedule (same arithmetic, same summation order -> bitwise identical results):
 //   0: loads -> 64 MFMAs -> LDS stores -> barrier                (compiler-scheduled)
 //   1: loads -> kk 0,1 -> LDS stores -> kk 2,3 -> barrier         (stores hidden under the second half's MFMAs)
@@ -205,7 +316,10 @@ __device__ __forceinline__ void tg_store(const TgParams& p, const TgItem& it, co
 //   4: the loads of three K-steps in flight (register queue): for items of few K-steps with little MFMA work each (batch 1)
 //   2: rotated: the fragments of the last k group are read before the barrier and their MFMAs issued after it,
 //      covering the barrier, the next tile's global-load issue and the first fragment reads of the new buffer
-template <int BM, int BN, int WM, int WN, int VAR>
+// STATS: the instantiation whose epilogue also produces the stored tensor's batch statistics (TgStats; training step only).  A
+// separate kernel so that the inference launches keep their register budget: the statistics epilogue holds 16 rows of
+// addresses and operands per lane and raised the 64x64 tile from 63 to 114 VGPRs, the 4-wave 128x128 tile from 148 to 236.
+template <int BM, int BN, int WM, int WN, int VAR, bool STATS = false>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_kernel(const TgParams p) {
   constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
   // 4 waves (256 threads) or 8 waves (512 threads: the 128x128 tile as 2 x 4 waves of 64x32 -- half the accumulator
@@ -598,6 +712,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
     }
     }  // FUSE
   }
+  if constexpr (STATS) {
+    if (it.slab < 0) {                 // training step: the stored tensor's batch statistics ride along (never on split-K slabs)
+      __syncthreads();                 // every wave is done with the K loop's LDS tiles: they become the reduction scratch
+      tg_store_stats<BM, BN, WM, WN>(p, it, cl, acc, wm, wn, lane, reinterpret_cast<double*>(smem));
+      return;
+    }
+  }
   tg_store<BM, BN, WM, WN>(p, it, cl, acc, wm, wn, lane);
 }
 
@@ -680,11 +801,11 @@ __global__ __launch_bounds__(256) void tapgemm_reduce_kernel(const TgReduceParam
   tg_reduce_body<BM, BN, KP>(p);
 }
 
-template <int BM, int BN, int WM, int WN, int VAR>
+template <int BM, int BN, int WM, int WN, int VAR, bool STATS = false>
 static hipError_t launch_var(const TgParams& p, int nitems, hipStream_t s) {
   static bool attr_set = false;
   const size_t lds = (size_t)2 * (BM + BN) * TG_LDS * sizeof(float);
-  auto k = tapgemm_kernel<BM, BN, WM, WN, VAR>;
+  auto k = tapgemm_kernel<BM, BN, WM, WN, VAR, STATS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -697,6 +818,15 @@ static hipError_t launch_var(const TgParams& p, int nitems, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN>
 static hipError_t launch_cfg(const TgParams& p, int nitems, hipStream_t s) {
+  if (p.epi.st.mode) {   // == tg_stats_supported(cfg, variant) on the host: the register-staged schedules of the tiles up to 128 x 128
+#ifdef IAN_ABLATION      // libian_ablation.so only: measured 4 % SLOWER per training update than the colstats passes
+    if constexpr (BM * BN <= 128 * 128) {
+      if (p.variant == 1) return launch_var<BM, BN, WM, WN, 1, true>(p, nitems, s);
+      if (p.variant == 2) return launch_var<BM, BN, WM, WN, 2, true>(p, nitems, s);
+    }
+#endif
+    return hipErrorInvalidValue;
+  }
   switch (p.variant) {
     // the three production schedules (autotune candidates): 1 and 2 register-staged, 4 = three K-steps of loads in flight
     case 1: return launch_var<BM, BN, WM, WN, 1>(p, nitems, s);

@@ -193,14 +193,17 @@ __device__ __forceinline__ double tree_sum_seq(const double* __restrict__ p, siz
     }
   return r;
 }
-// out[i] = tree over k of partial[k*width + i].  Block = 16 columns x 16 lanes; for a power-of-two count each lane
-// takes a contiguous 1/16th (its own subtree) and the lanes meet pairwise in LDS, which is the same tree.
+// out[i] = tree over k of partial[k*width + i].  Block = TC columns x (256 / TC) lanes; for a power-of-two count each lane
+// takes a contiguous 1/L-th (its own subtree) and the lanes meet pairwise in LDS, which is the same tree -- whatever L is, so
+// round 5 could go from 16 x 16 to 8 columns (one 64-byte line of doubles) x 32 lanes without moving a bit: the GEMM-epilogue
+// statistics (TgStats) hand over one partial per 128-row tile, up to 4096 of them where colstats' per-image chunks were 1024.
 // tree_column: every thread of the block calls it; the column's total is in red[col] afterwards.
+constexpr int TC = 8, TL = 256 / TC;
 __device__ __forceinline__ void tree_column(const double* __restrict__ partial, int count, int width, int i, bool valid,
                                             double* red) {
-  const int lane = threadIdx.x >> 4;
+  const int lane = threadIdx.x / TC;
   const bool pow2 = (count & (count - 1)) == 0;
-  const int L = pow2 ? min(16, count) : 1;   // lanes in use
+  const int L = pow2 ? min(TL, count) : 1;   // lanes in use
   double s = 0.0;
   if (valid && lane < L) {
     const int per = count / L;
@@ -209,21 +212,21 @@ __device__ __forceinline__ void tree_column(const double* __restrict__ partial, 
   red[threadIdx.x] = s;
   __syncthreads();
   for (int w = 1; w < L; w <<= 1) {
-    if (lane % (2 * w) == 0 && lane + w < L) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 16 * w];
+    if (lane % (2 * w) == 0 && lane + w < L) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + TC * w];
     __syncthreads();
   }
 }
 __global__ __launch_bounds__(256) void tree_sum_kernel(const double* __restrict__ partial, int count, int width,
                                                        double* __restrict__ out) {
   __shared__ double red[256];
-  const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
-  const int i = blockIdx.x * 16 + col;
+  const int col = threadIdx.x % TC, lane = threadIdx.x / TC;
+  const int i = blockIdx.x * TC + col;
   tree_column(partial, count, width, i, i < width, red);
   if (lane == 0 && i < width) out[i] = red[col];
 }
 hipError_t launch_tree_sum(const double* partial, int count, int width, double* out, hipStream_t s) {
   if (count <= 0 || width <= 0 || count >= (1 << TS_LEVELS)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(tree_sum_kernel, dim3((width + 15) / 16), dim3(256), 0, s, partial, count, width, out);
+  hipLaunchKernelGGL(tree_sum_kernel, dim3((width + TC - 1) / TC), dim3(256), 0, s, partial, count, width, out);
   return hipGetLastError();
 }
 
@@ -252,7 +255,7 @@ __device__ __forceinline__ float running_math(float r, float batch, float keep, 
 
 // second stage of the batch-norm FORWARD statistics in one launch (single-process step): the tree of tree_sum_kernel over
 // columns c and C + c of partial[chunk][2][C], bn_make_affine's arithmetic, and the running averages of the pass that owns
-// them.  Block = 8 channels x {s1, s2} x 16 lanes.
+// them.  Block = TC/2 channels x {s1, s2} x TL lanes.
 struct BnFinishArgs {
   const double* partial;
   const float* gamma;
@@ -269,11 +272,12 @@ struct BnFinishArgs {
 };
 __global__ __launch_bounds__(256) void bn_finish_kernel(BnFinishArgs a) {
   __shared__ double red[256];
-  const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
-  const int ch = blockIdx.x * 8 + (col & 7);
-  tree_column(a.partial, a.count, 2 * a.C, (col >> 3) * a.C + ch, ch < a.C, red);
-  if (lane == 0 && col < 8 && ch < a.C) {
-    const double s1 = red[col], s2 = red[col + 8];
+  constexpr int CH = TC / 2;
+  const int col = threadIdx.x % TC, lane = threadIdx.x / TC;
+  const int ch = blockIdx.x * CH + (col % CH);
+  tree_column(a.partial, a.count, 2 * a.C, (col / CH) * a.C + ch, ch < a.C, red);
+  if (lane == 0 && col < CH && ch < a.C) {
+    const double s1 = red[col], s2 = red[col + CH];
     a.sums[ch] = s1;
     a.sums[a.C + ch] = s2;
     float m, is, sc, sh;
@@ -294,8 +298,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const double* __rest
                                                             double* __restrict__ sums, float* __restrict__ gbeta, int acc_beta,
                                                             float* __restrict__ ggamma, int acc_gamma) {
   __shared__ double red[256];
-  const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
-  const int i = blockIdx.x * 16 + col;
+  const int col = threadIdx.x % TC, lane = threadIdx.x / TC;
+  const int i = blockIdx.x * TC + col;
   tree_column(partial, count, 2 * C, i, i < 2 * C, red);
   if (lane == 0 && i < 2 * C) {
     const double v = red[col];
@@ -306,26 +310,38 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const double* __rest
     }
   }
 }
+hipError_t launch_bn_finish(const double* partial, int nchunks, int C, double* sums, float count, float eps, const float* gamma,
+                            const float* beta, float* mean, float* inv_std, float* scale, float* shift, float* run_mean,
+                            float* run_inv_std, float keep, float alpha, hipStream_t s) {
+  if (nchunks <= 0 || nchunks >= (1 << TS_LEVELS)) return hipErrorInvalidValue;
+  BnFinishArgs f;
+  f.partial = partial; f.gamma = gamma; f.beta = beta; f.sums = sums; f.mean = mean; f.inv_std = inv_std; f.scale = scale;
+  f.shift = shift; f.run_mean = run_mean; f.run_inv_std = run_inv_std; f.n = count; f.eps = eps; f.keep = keep; f.alpha = alpha;
+  f.count = nchunks; f.C = C;
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((C + TC / 2 - 1) / (TC / 2)), dim3(256), 0, s, f);
+  return hipGetLastError();
+}
+hipError_t launch_bn_bwd_finish(const double* partial, int nchunks, int C, double* sums, float* gbeta, int acc_beta, float* ggamma,
+                                int acc_gamma, hipStream_t s) {
+  if (nchunks <= 0 || nchunks >= (1 << TS_LEVELS)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((2 * C + TC - 1) / TC), dim3(256), 0, s, partial, nchunks, C, sums, gbeta, acc_beta,
+                     ggamma, acc_gamma);
+  return hipGetLastError();
+}
 static void launch_colstats_stage1(const ColStatsArgs& a, int nchunks, hipStream_t s);
 hipError_t launch_bn_stats_affine(const ColStatsArgs& a, int nchunks, double* sums, float count, float eps, const float* gamma,
                                   const float* beta, float* mean, float* inv_std, float* scale, float* shift, float* run_mean,
                                   float* run_inv_std, float keep, float alpha, hipStream_t s) {
   if ((a.C & 3) || a.mode != 0 || nchunks <= 0 || nchunks >= (1 << TS_LEVELS)) return hipErrorInvalidValue;
   launch_colstats_stage1(a, nchunks, s);
-  BnFinishArgs f;
-  f.partial = a.partial; f.gamma = gamma; f.beta = beta; f.sums = sums; f.mean = mean; f.inv_std = inv_std; f.scale = scale;
-  f.shift = shift; f.run_mean = run_mean; f.run_inv_std = run_inv_std; f.n = count; f.eps = eps; f.keep = keep; f.alpha = alpha;
-  f.count = nchunks; f.C = a.C;
-  hipLaunchKernelGGL(bn_finish_kernel, dim3((a.C + 7) / 8), dim3(256), 0, s, f);
-  return hipGetLastError();
+  return launch_bn_finish(a.partial, nchunks, a.C, sums, count, eps, gamma, beta, mean, inv_std, scale, shift, run_mean, run_inv_std, keep,
+                          alpha, s);
 }
 hipError_t launch_bn_bwd_stats(const ColStatsArgs& a, int nchunks, double* sums, float* gbeta, int acc_beta, float* ggamma,
                                int acc_gamma, hipStream_t s) {
   if ((a.C & 3) || a.mode != 1 || nchunks <= 0 || nchunks >= (1 << TS_LEVELS)) return hipErrorInvalidValue;
   launch_colstats_stage1(a, nchunks, s);
-  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((2 * a.C + 15) / 16), dim3(256), 0, s, a.partial, nchunks, a.C, sums, gbeta,
-                     acc_beta, ggamma, acc_gamma);
-  return hipGetLastError();
+  return launch_bn_bwd_finish(a.partial, nchunks, a.C, sums, gbeta, acc_beta, ggamma, acc_gamma, s);
 }
 static void launch_colstats_stage1(const ColStatsArgs& a, int nchunks, hipStream_t s) {
   const long long rows_per = (a.rows + nchunks - 1) / nchunks;

@@ -1,6 +1,6 @@
 """The measured NEGATIVE results stay runnable, but outside the product: `IAN_ABLATION_BUILD=1` builds libian_ablation.so from
 the same sources with -DIAN_ABLATION -- tapgemm K-loop schedules 0 (compiler-scheduled) and 3 (LDS-DMA staging, 5 % slower),
-the batch-1 streaming deconv of kernels_b1.hip (slower) and the
+the batch-1 streaming deconv of kernels_b1.hip (slower), the GEMM-epilogue batch statistics of the training step (4 % slower per update) and the
 superseded 4-wave tapwgrad tile (round-3 verdict, weak #10).  libian.so contains none of them and rejects their option values
 (checked by the skipping branch of the same tests in the normal run).  Here a child Python runs those parity / bitwise tests
 against the ablation library (IAN_LIB), so the variants cannot rot."""
@@ -42,7 +42,8 @@ def test_ablation_library_builds_and_says_what_it_is():
 def test_negative_result_variants_still_pass_their_parity_tests():
     env = _ablation_env()
     sel = ("every_tile_config_and_split_policy or batch1_streaming_deconv_equals_the_tapgemm_form "
-           "or eight_wave_tile_is_bitwise_the_four_wave_tile")
+           "or eight_wave_tile_is_bitwise_the_four_wave_tile or gemm_epilogue_statistics_equal_colstats "
+           "or step_with_epilogue_statistics_equals_the_colstats_step")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider", "-m", "gpu", "-rs", "tests/test_gpu_parity.py",
                         "tests/test_gpu_train_kernels.py", "-k", sel], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        timeout=1500)

@@ -226,9 +226,17 @@ def test_training_functions_vs_reference_train_IAN():
     # Parameters after the two updates, PER TENSOR against the reference's end point (round-4 verdict item 6; the round-4 bar
     # was one aggregate, err.mean() < 0.1 * moved.mean(), which a sign error on a minority of tensors would have passed).
     # Adam's first step is sign-like -- |step| = lr whatever |g| -- so an element lands 2 lr away from the reference exactly
-    # when its gradient's sign differs, i.e. when |g| is below the implementation's error: the mean |after - reference| of a
-    # tensor is 2 lr x (fraction of flipped elements), held to 2 lr x (the tensor's own float32 noise in the reference's graph
-    # + 1e-3).  Z_params take two steps (gen then discrim0's successor): their bound uses the larger of the two recorded noises.
+    # when its gradient's sign differs, i.e. when |g| is below the implementation's error: mean |after - reference| of a tensor
+    # is 2 lr x (fraction of elements on the other side).
+    #   * decoder_params are stepped ONCE, from the initial parameters (update_gen): held to 2 lr x (the tensor's own float32
+    #     noise in the reference's graph + 1e-3), with a floor of 2.5 elements per tensor (a 256-element coefficient vector whose
+    #     smallest gradient flips is 1/256 = 4e-3 on its own; measured: exactly such single elements, 17 tensors of 82 over the
+    #     unfloored bound, profiles/r05_reference_pinned_errors.json);
+    #   * encoder_params and Z_params are touched by the SECOND update, whose forward already runs on parameters that differ
+    #     from the reference's by the first step's flipped elements -- their gradients are a different draw, for which the fixture
+    #     holds no noise figure (discrim0 is the discriminator step from the INITIAL parameters): held to <= 10 % of the elements
+    #     on the other side (0.2 lr; measured worst 4.2 % on the 256-element bnorm2.gamma).
+    # A sign error on one whole tensor puts ALL its elements 2 lr away: 10x to 500x above either bar.
     after = tr.params_numpy()
     moved, per = [], {}
     for key in fx.files:
@@ -236,12 +244,19 @@ def test_training_functions_vs_reference_train_IAN():
             n = key[6:]
             ref = np.asarray(fx[key], np.float64)
             moved.append(np.abs(ref - np.asarray(P[n], np.float64)).ravel())
-            nz = max([float(fx["%s/noise32/%s" % (tag, n)]) for tag in ("gen", "discrim0") if "%s/noise32/%s" % (tag, n) in fx.files] or [0.0])
-            per[n] = (float(np.abs(after[n] - ref).mean()), 2 * tr.lr * (nz + 1e-3), nz)
+            e = float(np.abs(after[n] - ref).mean())
+            if tr.where[n] == "dec":
+                nz = float(fx["gen/noise32/" + n])
+                bound = 2 * tr.lr * max(nz + 1e-3, 2.5 / ref.size)
+            else:
+                nz = max([float(fx["%s/noise32/%s" % (tag, n)]) for tag in ("gen", "discrim0") if "%s/noise32/%s" % (tag, n) in fx.files] or [0.0])
+                bound = 0.2 * tr.lr
+            per[n] = (e, bound, nz, tr.where[n], int(ref.size))
     moved = np.concatenate(moved)
-    bad = sorted(((e / b, e, b, nz, n) for n, (e, b, nz) in per.items() if e > b), reverse=True)
+    bad = sorted(((e / b, e, b, nz, g, n) for n, (e, b, nz, g, sz) in per.items() if e > b), reverse=True)
     _note("post_update_param_err", {"lr": tr.lr, "tensors": len(per), "over_bound": bad,
-                                    "worst_ratio_to_bound": sorted(((e / b, e, nz, n) for n, (e, b, nz) in per.items()), reverse=True)[:8]})
+                                    "fraction_of_elements_on_the_other_side": sorted(((e / (2 * tr.lr), g, sz, n) for n, (e, b, nz, g, sz) in per.items()), reverse=True)[:12],
+                                    "worst_ratio_to_bound": sorted(((e / b, e, nz, g, n) for n, (e, b, nz, g, sz) in per.items()), reverse=True)[:8]})
     assert moved.mean() > 0.5 * tr.lr, moved.mean()
     assert len(per) >= 60 and not bad, bad[:6]
     untouched = [n for n in fx["untrained"].tolist() if n.startswith("l_IAF")]
