@@ -72,7 +72,8 @@ class IAN:
     # ---- helpers -------------------------------------------------------------------------------------
     @staticmethod
     def _f32(a, shape_tail, what):
-        a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        if not (type(a) is np.ndarray and a.dtype == np.float32 and a.flags.c_contiguous):    # the interactive loop passes ready arrays
+            a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
         if a.ndim != len(shape_tail) + 1 or tuple(a.shape[1:]) != tuple(shape_tail):
             raise ValueError("%s must have shape (n,%s), got %s" % (what, ",".join(map(str, shape_tail)), a.shape))
         if a.shape[0] < 1:
@@ -142,7 +143,6 @@ class IAN:
         -> (z_new (1,zdim), image (1,3,64,64) or None)  or, with photo=(RECON uint8, ERROR float32),
            (z_new, image or None, IM uint8 (3,64,64), MASK float64 (64,64) if want_mask else None)  (photo mode,
            NPE.py:218-231; NPE.paint itself only displays IM, so the 32 KB mask stays on the device unless asked for)."""
-        from . import npe_ops
         z = self._f32(z, (self._zdim,), "z")
         rgb = self._f32(RGB, (3, 64, 64), "RGB")[:1] if RGB is not None else None
         z_new = np.empty((1, self._zdim), np.float32)
@@ -153,6 +153,7 @@ class IAN:
             err = np.ascontiguousarray(photo[1], dtype=np.float32)
             if recon.shape != (3, 64, 64) or err.shape != (3, 64, 64):
                 raise ValueError("RECON and ERROR must have shape (3,64,64)")
+            from . import npe_ops
             half = npe_ops.gaussian_half_kernel(sigma, int(4.0 * float(sigma) + 0.5))
             im, mask = np.empty((3, 64, 64), np.uint8), (np.empty((64, 64), np.float64) if want_mask else None)
             pa = (recon, err, half, im, mask)

@@ -440,20 +440,29 @@ __global__ __launch_bounds__(256) void deconv_out_bwd_kernel(const float* __rest
 // output activation's derivative and the backward-data of the image-producing transposed conv.  The seed is non-zero
 // only inside the rectangle, so a thread visits only the taps whose output pixel lies in it (most threads: none).
 //   gout[co,oy,ox] = seed(co,oy,ox) * act'(xhat) * oscale[co];   dx[iy,ix,ci] = (sum_{taps in patch} gout * w) * act_in'(yfwd) * scale[ci]
+// Round 5: in the captured brush event `patch` lives in the mapped PINNED HOST block (zero-copy graphs), and round 4's form --
+// every thread reading patch[0..3], i.e. one scalar load over PCIe per wave, 2048 waves -- made this the longest kernel of the
+// event: 19.0 us (profiles/r05_batch1_chains.md, first pass).  Now ONE lane per workgroup fetches the rectangle and hands it on
+// through LDS, and a thread owns four consecutive channels of a pixel (128 workgroups instead of 512, float4 filter loads and
+// stores).  Same products in the same order per element: bitwise the round-4 gradient.
 __global__ __launch_bounds__(256) void deconv_out_bwd_seed_kernel(const float* __restrict__ xhat, const float* __restrict__ rgb,
                                                                   const int* __restrict__ patch, int mode, int out_act,
                                                                   const float* __restrict__ oscale, const float* __restrict__ w,
                                                                   float* __restrict__ dx, const float* __restrict__ yfwd,
                                                                   const float* __restrict__ scale, int H, int W, int Cin,
                                                                   int Cout, int act) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= H * W * Cin) return;
-  const int ci = idx % Cin, pix = idx / Cin;
+  __shared__ int sp[4];
+  if (threadIdx.x < 4) sp[threadIdx.x] = patch[threadIdx.x];
+  __syncthreads();
+  const int c4n = Cin >> 2;
+  const int idx4 = blockIdx.x * 256 + threadIdx.x;
+  if (idx4 >= H * W * c4n) return;
+  const int ci = (idx4 % c4n) * 4, pix = idx4 / c4n;
   const int ix = pix % W, iy = pix / W;
   const int OH = 2 * H, OW = 2 * W;
-  const int c1 = patch[0], r1 = patch[1], c2 = patch[2], r2 = patch[3];
+  const int c1 = sp[0], r1 = sp[1], c2 = sp[2], r2 = sp[3];
   const int cnt = 3 * (r2 - r1) * (c2 - c1);
-  float acc = 0.f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (cnt > 0) {
     const float inv = 1.f / (float)cnt;
     const int ky0 = max(0, r1 - (2 * iy - 2)), ky1 = min(5, r2 - (2 * iy - 2));
@@ -469,18 +478,30 @@ __global__ __launch_bounds__(256) void deconv_out_bwd_seed_kernel(const float* _
           const float xh = xhat[o];
           float gv = (mode == 0) ? inv : 2.f * (xh - rgb[o]) * inv;
           gv = gv * m_dact(xh, out_act) * (oscale ? oscale[co] : 1.f);
-          acc = fmaf(gv, w[((size_t)(ky * 5 + kx) * 4 + co) * Cin + ci], acc);
+          const float4 wv = *reinterpret_cast<const float4*>(w + ((size_t)(ky * 5 + kx) * 4 + co) * Cin + ci);
+          acc[0] = fmaf(gv, wv.x, acc[0]);
+          acc[1] = fmaf(gv, wv.y, acc[1]);
+          acc[2] = fmaf(gv, wv.z, acc[2]);
+          acc[3] = fmaf(gv, wv.w, acc[3]);
         }
       }
     }
   }
-  const float d = yfwd ? m_dact(yfwd[idx], act) : 1.f;
-  dx[idx] = acc * d * (scale ? scale[ci] : 1.f);
+  const size_t o4 = (size_t)pix * Cin + ci;
+  float4 out;
+  float* op = &out.x;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float d = yfwd ? m_dact(yfwd[o4 + e], act) : 1.f;
+    op[e] = acc[e] * d * (scale ? scale[ci + e] : 1.f);
+  }
+  *reinterpret_cast<float4*>(dx + o4) = out;
 }
 hipError_t launch_deconv_out_bwd_seed(const float* xhat, const float* rgb, const int* patch, int mode, int out_act,
                                       const float* oscale, const float* w, float* dx, const float* yfwd, const float* scale, int H,
                                       int W, int Cin, int Cout, int act, hipStream_t s) {
-  const int total = H * W * Cin;
+  if (Cin & 3) return hipErrorInvalidValue;
+  const int total = H * W * (Cin >> 2);
   hipLaunchKernelGGL(deconv_out_bwd_seed_kernel, dim3((total + 255) / 256), dim3(256), 0, s, xhat, rgb, patch, mode, out_act, oscale,
                      w, dx, yfwd, scale, H, W, Cin, Cout, act);
   return hipGetLastError();
@@ -518,6 +539,9 @@ __global__ __launch_bounds__(256) void dense_bwd_gemv_kernel(const float* __rest
   __shared__ float part[4];
   const int row = blockIdx.x;
   const float* wr = wb + (size_t)row * K;
+  // (coef, gscale) may live in mapped host memory: requested first, so that the PCIe round trip runs under the weight stream
+  float cg0 = 0.f, cg1 = 0.f, zrow = 0.f;
+  if (threadIdx.x == 0 && upd.z) { cg0 = upd.cg[0]; cg1 = upd.cg[1]; zrow = upd.z[row]; }
   float acc = 0.f;
 #pragma unroll 8
   for (int k = threadIdx.x * 4; k < K; k += 1024) {
@@ -537,7 +561,7 @@ __global__ __launch_bounds__(256) void dense_bwd_gemv_kernel(const float* __rest
     if (res) v += res[row];
     dz[row] = v;
     if (upd.z) {
-      const float zn = latent_step(upd.z[row], v, upd.cg[0], upd.cg[1]);
+      const float zn = latent_step(zrow, v, cg0, cg1);
       upd.z[row] = zn;
       if (upd.z_mirror) upd.z_mirror[row] = zn;
       if (upd.g_mirror) upd.g_mirror[row] = v;
@@ -769,9 +793,12 @@ __global__ __launch_bounds__(256) void patch_seed_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void patch_seed_dev_kernel(const float* __restrict__ xhat, const float* __restrict__ rgb,
                                                              float* __restrict__ g, int H, int W, const int* __restrict__ patch,
                                                              int mode) {
+  __shared__ int sp[4];   // `patch` may live in mapped host memory (zero-copy graphs): one fetch per workgroup, not one per wave
+  if (threadIdx.x < 4) sp[threadIdx.x] = patch[threadIdx.x];
+  __syncthreads();
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 3 * H * W) return;
-  const int c1 = patch[0], r1 = patch[1], c2 = patch[2], r2 = patch[3];
+  const int c1 = sp[0], r1 = sp[1], c2 = sp[2], r2 = sp[3];
   const int xx = i % W, yy = (i / W) % H;
   const int cnt = 3 * (r2 - r1) * (c2 - c1);
   float v = 0.f;

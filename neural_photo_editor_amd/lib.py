@@ -132,7 +132,7 @@ class IanError(RuntimeError):
 def _ptr(buf):
     """Raw address of a numpy array (host) or of anything exposing data_ptr() (torch device tensor)."""
     if isinstance(buf, np.ndarray):
-        return C.c_void_p(buf.ctypes.data)
+        return C.c_void_p(buf.__array_interface__["data"][0])    # (ndarray.ctypes builds a helper object per access: ~1 us each)
     if hasattr(buf, "data_ptr"):
         return C.c_void_p(buf.data_ptr())
     if isinstance(buf, int):
