@@ -165,7 +165,9 @@ class NativeRcclComm(Comm):
                 rc = lib.ian_rccl_comm_add_gather(C.byref(o), C.create_string_buffer(ids[1], 128))
                 if rc:
                     why = "ian_rccl_comm_add_gather failed (%d): %s" % (rc, err())
-                ok = rc == 0
+                else:
+                    why = self._preflight(torch, o)
+                ok = not why
         elif host:
             why = "host buffers requested"
         if self.world > 1:                         # all ranks take the same route
@@ -183,6 +185,35 @@ class NativeRcclComm(Comm):
         self.filler = "torch.distributed (fallback: %s)" % why
         self.gather_group = self.dist.new_group(ranks=self.dist.get_process_group_ranks(self.group) if self.group is not None else None)
         return Comm.ops(self, torch, host=host)
+
+    def _preflight(self, torch, o):
+        """One all-reduce and one all-gather of known values through the freshly filled table, each on its own side stream, before
+        the trainer sees it: the local NCCL ABI declarations of csrc/ian_comm_rccl.cpp (datatype / reduction codes, argument
+        order) are only exercised with more than one rank here, and a wrong sum must send every rank to the torch.distributed
+        filler instead of into the gradients.  Returns "" or the reason."""
+        try:
+            w, r, n = self.world, self.rank, 1024
+            s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+            with torch.cuda.stream(s1):
+                a = torch.full((n,), float(r + 1), device="cuda")
+            with torch.cuda.stream(s2):
+                src = torch.full((n,), float(r + 1), device="cuda")
+                dst = torch.zeros(w * n, device="cuda")
+            torch.cuda.synchronize()
+            rcs = (o.allreduce_sum(o.ctx, a.data_ptr(), n, s1.cuda_stream),
+                   o.allgather(o.ctx, src.data_ptr(), dst.data_ptr(), n, s2.cuda_stream),
+                   o.wait_all(o.ctx, s2.cuda_stream))
+            torch.cuda.synchronize()
+            if any(rcs):
+                return "preflight collective failed %s: %s" % (rcs, (self._lib.ian_rccl_last_error() or b"?").decode())
+            want = torch.arange(1, w + 1, device="cuda", dtype=torch.float32).repeat_interleave(n)
+            if not bool((a == w * (w + 1) / 2).all()):
+                return "preflight all-reduce returned %r, expected %r" % (float(a[0]), w * (w + 1) / 2)
+            if not torch.equal(dst, want):
+                return "preflight all-gather returned wrong rows"
+            return ""
+        except BaseException as exc:              # noqa: BLE001 -- every rank must reach the agreement below
+            return "preflight raised %r" % (exc,)
 
     def close(self):
         if getattr(self, "_native_ops", None) is not None:

@@ -12,6 +12,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _free_port():
     s = socket.socket()
@@ -153,3 +155,41 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 3 and out["dry_run"] is True
+
+
+def test_local_rccl_abi_declarations_match_the_installed_header():
+    """csrc/ian_comm_rccl.cpp declares the slice of the NCCL ABI it calls itself (no rccl.h at build time) and
+    resolves the entry points with dlopen; with more than one rank those declarations run for the first time on the 8-GPU node, so
+    they are pinned here against the header of the RCCL this image ships: id size, result / datatype / reduction codes and the
+    argument lists of the five entry points."""
+    import re
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        pytest.skip("no rccl.h in this image")
+    h = open(hdr).read()
+    src = open(os.path.join(ROOT, "neural_photo_editor_amd", "csrc", "ian_comm_rccl.cpp")).read()
+    const = lambda name: int(re.search(r"\b%s\s*=\s*(\d+)" % name, src).group(1))
+    assert int(re.search(r"#define\s+NCCL_UNIQUE_ID_BYTES\s+(\d+)", h).group(1)) == const("kIdBytes") == 128
+    assert re.search(r"typedef struct \{ char internal\[NCCL_UNIQUE_ID_BYTES\];", h)          # passed BY VALUE to ncclCommInitRank
+    for ours, theirs in (("kRcclSuccess", "ncclSuccess"), ("kRcclFloat32", "ncclFloat32"), ("kRcclSum", "ncclSum")):
+        assert int(re.search(r"\b%s\s*=\s*(\d+)" % theirs, h).group(1)) == const(ours), theirs
+
+    def header_args(fn):
+        m = re.search(r"ncclResult_t\s+%s\(([^;]*?)\);" % fn, h, re.S)
+        kinds = []
+        for a in m.group(1).split(","):
+            t = " ".join(a.split()[:-1]).replace("const ", "")            # drop the parameter name
+            star = "*" in a
+            kinds.append({"void": "ptr", "ncclUniqueId": "id*" if star else "id", "ncclComm_t": "comm*" if star else "comm", "int": "int",
+                          "size_t": "size", "ncclDataType_t": "int", "ncclRedOp_t": "int", "hipStream_t": "stream"}[t.replace("*", "").strip()])
+        return kinds
+
+    def our_args(member):
+        m = re.search(r"\(\*%s\)\(([^)]*)\)" % member, src)
+        return [{"const void*": "ptr", "void*": "ptr", "RcclUniqueId*": "id*", "RcclUniqueId": "id", "RcclComm*": "comm*", "RcclComm": "comm",
+                 "int": "int", "size_t": "size", "hipStream_t": "stream"}[a.strip()] for a in m.group(1).split(",")]
+
+    for member, fn in (("GetUniqueId", "ncclGetUniqueId"), ("CommInitRank", "ncclCommInitRank"), ("CommDestroy", "ncclCommDestroy"),
+                       ("AllReduce", "ncclAllReduce"), ("AllGather", "ncclAllGather")):
+        assert our_args(member) == header_args(fn), (fn, our_args(member), header_args(fn))
+        assert '"%s"' % fn in src                                                              # the name handed to dlsym
