@@ -188,6 +188,13 @@ int ian_autotune(ian_handle* h, int32_t n, int32_t what, void* stream);
 /* Tuning knobs (tile shape / split-K policy); key=value, returns <0 on unknown key. */
 int ian_set_option(ian_handle* h, const char* key, int32_t value);
 
+/* Box fingerprint for the bench line (no reference counterpart: the reference has no measurement code; it makes driver numbers
+   from different boxes comparable).  Runs `launches` back-to-back launches of a register-only v_mfma_f32_32x32x2_f32 loop of
+   `iters` x 4 MFMAs per wave (2 workgroups of 4 waves on each of the 256 CUs, non-zero operands, no memory traffic) on the
+   current device's `stream` and returns the sustained fp32 matrix rate in TFLOP/s and the mean launch duration in microseconds.
+   iters = 1600 gives launches of ~200 us (one IAN_simple batch-64 layer), 6400 ~700 us.  Needs no handle.  0 = ok, <0 = HIP error. */
+int ian_box_probe(int32_t iters, int32_t launches, double* tflops, double* us_per_launch, void* stream);
+
 const char* ian_last_error(ian_handle* h);
 const char* ian_version(void);
 void ian_destroy(ian_handle* h);

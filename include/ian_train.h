@@ -254,7 +254,19 @@ int ian_trainer_set_comm(ian_trainer* t, const ian_comm_ops* ops, int32_t exact)
    from ian_rccl_unique_id, every rank, blocks like comm_create) gives the all-gathers their OWN communicator: one communicator
    runs its collectives in issue order whatever streams they are on, so without it a batch-statistics all-gather the compute
    stream blocks on queues behind every gradient bucket already handed over.  0 / negative (-10: librccl could not be loaded),
-   text via ian_rccl_last_error. */
+   text via ian_rccl_last_error.
+   CONTRACT for callers that add the second communicator (two communicators on one device are only deadlock-free under it):
+   (1) every rank issues the SAME sequence of collectives on each communicator -- the trainer guarantees that when every rank
+   passes the same configuration, batch, `which` sequence and `exact` flag (the bucket plan and the all-gather sites depend on
+   nothing else; the loss all-reduce is unconditional, see ian_train_step); (2) the all-gather kernels (compute stream) and the
+   bucket all-reduce kernels (side stream) must be able to be co-resident on every GPU: RCCL's kernels are small persistent
+   grids, and the trainer never launches a cooperative or grid-barrier kernel of its own, so a tap-GEMM occupying the chip only
+   delays them.  A job that cannot guarantee (1)/(2) -- or that has hung once -- runs WITHOUT ian_rccl_comm_add_gather: one
+   communicator serialises everything in issue order (slower by the queueing described above, never deadlocks on ordering);
+   trainer.NativeRcclComm(one_comm=True) / IAN_RCCL_ONE_COMM=1 select that mode and bench.py falls back to it by itself.
+   ian_rccl_available: 0 when librccl can be loaded and exports the seven entry points (no communicator is touched, never
+   blocks) -- call it on every rank and agree on the outcome BEFORE any rank enters the blocking ian_rccl_comm_create. */
+int ian_rccl_available(void);
 int ian_rccl_unique_id(void* out128);
 int ian_rccl_comm_create(const void* id128, int32_t rank, int32_t world, ian_comm_ops* ops);
 int ian_rccl_comm_add_gather(ian_comm_ops* ops, const void* id128);

@@ -80,6 +80,11 @@ class IAN:
             raise ValueError("%s is empty" % what)
         return a
 
+    def _grad_out(self, z):
+        """API.py:59,64 differentiate a loss on X_hat[0] with respect to the WHOLE Z: the result has Z's shape (n, zdim) and, the
+        decoder being deterministic (per-sample), rows 1.. are exactly zero.  NPE.py only ever passes n = 1."""
+        return np.empty((1, self._zdim), np.float32) if z.shape[0] == 1 else np.zeros((z.shape[0], self._zdim), np.float32)
+
     def _run(self, fn, src, out_tail):
         out = np.empty((src.shape[0],) + tuple(out_tail), np.float32)
         self._h.call(fn, src, src.shape[0], out)
@@ -89,16 +94,16 @@ class IAN:
     def imgrad(self, c1, r1, c2, r2, z):
         """API.py:66-70: change in latents which would lighten the local image patch."""
         z = self._f32(z, (self._zdim,), "z")
-        dz = np.empty((1, self._zdim), np.float32)
-        self._h.grad_light(int(c1), int(r1), int(c2), int(r2), z[:1], dz)
+        dz = self._grad_out(z)
+        self._h.grad_light(int(c1), int(r1), int(c2), int(r2), z[:1], dz[:1])
         return dz
 
     def imgradRGB(self, c1, r1, c2, r2, RGB, z):
         """API.py:72-76: change in latents which would move the patch towards RGB."""
         z = self._f32(z, (self._zdim,), "z")
         rgb = self._f32(RGB, (3, 64, 64), "RGB")
-        dz = np.empty((1, self._zdim), np.float32)
-        self._h.grad_rgb(int(c1), int(r1), int(c2), int(r2), rgb[:1], z[:1], dz)
+        dz = self._grad_out(z)
+        self._h.grad_rgb(int(c1), int(r1), int(c2), int(r2), rgb[:1], z[:1], dz[:1])
         return dz
 
     def encode_images(self, images):

@@ -28,8 +28,11 @@ if ABLATION:
 # AddressSanitizer + UBSan with guard bands around every device allocation (csrc/ian_guard.h); the .hip objects are the
 # product build's.  Loaded by tests through IAN_LIB=<path> with the ASan runtime preloaded (tests/test_sanitize.py).
 SANITIZE = bool(os.environ.get("IAN_SANITIZE")) and not ABLATION
-LIB = os.path.join(HERE, "libian_ablation.so" if ABLATION else ("libian_asan.so" if SANITIZE else "libian.so"))
-STAMP = os.path.join(HERE, ".libian_ablation.stamp" if ABLATION else (".libian_asan.stamp" if SANITIZE else ".libian.stamp"))
+# IAN_NOFUSE_BUILD=1 (scripts/exp/tgfuse_ab.py): libian_nofuse.so = the product sources with -DIAN_NO_TG_FUSE, i.e. the small tap-GEMM
+# tiles WITHOUT round 5's in-launch split-K combine epilogue (their round-4 object code), for an in-process A/B against libian.so.
+NOFUSE = bool(os.environ.get("IAN_NOFUSE_BUILD")) and not ABLATION and not SANITIZE
+LIB = os.path.join(HERE, "libian_ablation.so" if ABLATION else ("libian_asan.so" if SANITIZE else ("libian_nofuse.so" if NOFUSE else "libian.so")))
+STAMP = os.path.join(HERE, ".libian_ablation.stamp" if ABLATION else (".libian_asan.stamp" if SANITIZE else (".libian_nofuse.stamp" if NOFUSE else ".libian.stamp")))
 HOST_SOURCES = ("ian_runtime.cpp", "ian_train_abi.cpp", "ian_trainer.cpp", "ian_comm_rccl.cpp")
 # The host units contain no device code (they call the launch_* wrappers of the .hip files), so the sanitized build compiles
 # them with g++ against the HIP runtime API: GCC's ASan runtime, unlike ROCm clang's, does not intercept the HSA allocator
@@ -75,6 +78,7 @@ def _digest(scope=None):
     h.update(ARCH.encode())
     h.update(b"ablation" if ABLATION else b"")
     h.update(b"sanitize-g++-libasan" if SANITIZE else b"")
+    h.update(b"no-tg-fuse" if NOFUSE else b"")
 
     return h.hexdigest()
 
@@ -121,7 +125,7 @@ def build(force=False, verbose=False):
 def _build_locked(dig, verbose):
     hipcc = _hipcc()
     objs = []
-    bdir = os.path.join(HERE, "build_ablation" if ABLATION else "build")
+    bdir = os.path.join(HERE, "build_ablation" if ABLATION else ("build_nofuse" if NOFUSE else "build"))
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for src in SOURCES:
@@ -129,6 +133,8 @@ def _build_locked(dig, verbose):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if ABLATION:
             cmd.insert(1, "-DIAN_ABLATION")
+        if NOFUSE:
+            cmd.insert(1, "-DIAN_NO_TG_FUSE")
         if SANITIZE:
             if src not in HOST_SOURCES:
                 if not os.path.exists(obj):

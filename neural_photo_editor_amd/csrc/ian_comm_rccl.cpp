@@ -90,20 +90,25 @@ int cb_allreduce(void* c, float* buf, int64_t count, void* stream) {
   Api* a = api();
   if (!x || !a || !buf || count <= 0) return 1;
   const hipStream_t st = (hipStream_t)stream;
+  // the event wait_all will need for this stream is secured BEFORE the collective is issued: a failure here must not leave an
+  // all-reduce in flight that nothing tracks
+  bool tracked = false;
+  for (auto& p : x->pending)
+    if (p.first == st) tracked = true;
+  if (!tracked) {
+    hipEvent_t e = nullptr;
+    if (!x->free_events.empty()) {
+      e = x->free_events.back();
+      x->free_events.pop_back();
+    } else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      g_rccl_err = "hipEventCreateWithFlags failed in allreduce_sum (nothing was issued)";
+      return 1;
+    }
+    x->pending.push_back({st, e});
+  }
   const RcclResult r = a->AllReduce(buf, buf, (size_t)count, kRcclFloat32, kRcclSum, x->comm, st);
   if (r != kRcclSuccess) return fail("ncclAllReduce", r);
-  for (auto& p : x->pending)
-    if (p.first == st) return 0;
-  hipEvent_t e = nullptr;
-  if (!x->free_events.empty()) {
-    e = x->free_events.back();
-    x->free_events.pop_back();
-  } else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
-    (void)hipGetLastError();
-    g_rccl_err = "hipEventCreateWithFlags failed in allreduce_sum";
-    return 1;
-  }
-  x->pending.push_back({st, e});
   return 0;
 }
 int cb_wait_all(void* c, void* stream) {
@@ -136,6 +141,14 @@ int cb_allgather(void* c, const float* src, float* dst, int64_t count, void* str
 extern "C" {
 
 const char* ian_rccl_last_error(void) { return g_rccl_err.c_str(); }
+
+/* every rank, before anything else: can librccl be loaded at all?  Touches no communicator and never blocks, so the ranks can agree on
+   the outcome before any of them enters ncclCommInitRank (which blocks until ALL ranks have arrived).  0 / -10. */
+int ian_rccl_available(void) {
+  if (api()) return 0;
+  g_rccl_err = "librccl.so could not be loaded (dlopen) or lacks an entry point";
+  return -10;
+}
 
 /* rank 0: 128 bytes to hand to every rank (ncclGetUniqueId).  -10: librccl could not be loaded. */
 int ian_rccl_unique_id(void* out128) {

@@ -121,6 +121,10 @@ static inline TgShape tg_shape(int cfg) {
 // tile configurations whose kernel carries the in-launch split-K combine (TgParams::fused != 0): the small 4-wave tiles the
 // batch-1 chains use.  The large tiles are compiled WITHOUT that epilogue (it cost the 256x128 tile 95 spilled VGPRs).
 static inline bool tg_fuse_supported(int cfg) {
+#ifdef IAN_NO_TG_FUSE   // libian_nofuse.so: the epilogue is compiled out of every tile (A/B build, build.py)
+  (void)cfg;
+  return false;
+#endif
   return cfg == TG_32x128 || cfg == TG_64x64 || cfg == TG_128x64 || cfg == TG_128x32;
 }
 
@@ -160,6 +164,8 @@ struct B1Params {
 hipError_t launch_b1conv(const B1Params& p, int mode, hipStream_t s);
 
 hipError_t launch_tapgemm(int cfg, const TgParams& p, int nitems, hipStream_t s);
+// ian_box_probe: register-only fp32-MFMA loop, `blocks` workgroups of 256 threads, 4 x iters MFMAs per wave (kernels_misc.hip)
+hipError_t launch_box_probe(const float* in, float* out, int blocks, int iters, hipStream_t s);
 // kp > 1: four lanes share the slabs of one output element (few tiles, many slabs: batch 1)
 hipError_t launch_tapgemm_reduce(int cfg, const TgReduceParams& p, int ntiles, int kp, hipStream_t s);
 

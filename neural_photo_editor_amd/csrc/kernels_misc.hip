@@ -1260,4 +1260,31 @@ hipError_t launch_beta_bwd(const float* gout, const BetaBwdArgs& a, int n, int h
   return hipGetLastError();
 }
 
+
+// ---- ian_box_probe (include/ian.h): what the fp32 matrix pipe of THIS box sustains ------------------------------------------------
+// v_mfma_f32_32x32x2_f32 issued back to back from registers (four independent accumulators per wave, 2 workgroups of 4 waves per CU,
+// non-zero operands, no memory traffic inside the loop).  Launched back to back with a chosen loop length: the part clocks down under
+// fp32-MFMA load and every launch carries a clock / fill ramp, so the figure depends on the launch length -- the bench line quotes it
+// at the launch length of one IAN_simple batch-64 layer (~200 us) next to the spec peak.
+typedef float f32x16_probe __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void box_probe_kernel(const float* __restrict__ in, float* __restrict__ out, int iters) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const float a0 = in[t * 4 + 0], a1 = in[t * 4 + 1], b0 = in[t * 4 + 2], b1 = in[t * 4 + 3];
+  f32x16_probe c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, c3, 0, 0, 0);
+  }
+  float s = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += c0[r] + c1[r] + c2[r] + c3[r];
+  out[t] = s;
+}
+hipError_t launch_box_probe(const float* in, float* out, int blocks, int iters, hipStream_t s) {
+  hipLaunchKernelGGL(box_probe_kernel, dim3(blocks), dim3(256), 0, s, in, out, iters);
+  return hipGetLastError();
+}
+
 }  // namespace ian

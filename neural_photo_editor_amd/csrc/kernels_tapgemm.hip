@@ -598,7 +598,12 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
 
   // ---- epilogue. C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
   if (it.slab >= 0) {
+#ifdef IAN_NO_TG_FUSE   // libian_nofuse.so (IAN_NOFUSE_BUILD=1, scripts/exp/tgfuse_ab.py): the round-5 in-launch combine epilogue compiled OUT
+                        // of every tile -- the round-4 object code of the small tiles, for the in-process A/B the round-5 verdict asked for
+    constexpr bool FUSE = false;
+#else
     constexpr bool FUSE = WM * WN == 4 && BM * BN <= 128 * 64;   // == tg_fuse_supported(cfg): the host never asks the others
+#endif
     if (!FUSE || p.fused == 0) {   // split-K, separate reduce launch: row-major slab tile
       float* sl = p.slab + (size_t)it.slab * (BM * BN);
       const int col_l = lane & 31;

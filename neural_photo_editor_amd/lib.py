@@ -43,7 +43,7 @@ EXPORTS = (
     "ian_create", "ian_load_param", "ian_set_made_masks", "ian_finalize", "ian_encode", "ian_decode",
     "ian_encode_pre_iaf", "ian_iaf", "ian_reconstruct", "ian_grad_rgb", "ian_grad_light", "ian_decode_u8", "ian_photo_blend",
     "ian_read_slot", "ian_read_slot_grad",
-    "ian_brush_step", "ian_profile_enable", "ian_profile_read", "ian_autotune", "ian_set_option", "ian_last_error", "ian_version", "ian_destroy",
+    "ian_brush_step", "ian_profile_enable", "ian_profile_read", "ian_autotune", "ian_set_option", "ian_box_probe", "ian_last_error", "ian_version", "ian_destroy",
 )
 
 _lib = None
@@ -107,6 +107,7 @@ def load_library():
                                      C.POINTER(C.c_double)]
     lib.ian_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.ian_autotune.argtypes = [vp, i32, i32, vp]
+    lib.ian_box_probe.argtypes = [i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
     lib.ian_last_error.argtypes = [vp]
     lib.ian_last_error.restype = C.c_char_p
     lib.ian_version.restype = C.c_char_p
@@ -127,6 +128,17 @@ class PhotoArgs(C.Structure):
 
 class IanError(RuntimeError):
     pass
+
+
+def box_probe(iters=1600, launches=250, stream=None):
+    """ian_box_probe: sustained fp32-MFMA rate of this box (register-only loop, launches of ~200 us at iters = 1600).
+    -> {"tflops": ..., "us_per_launch": ...}"""
+    lib = load_library()
+    tf, us = C.c_double(), C.c_double()
+    rc = lib.ian_box_probe(int(iters), int(launches), C.byref(tf), C.byref(us), C.c_void_p(stream or 0))
+    if rc != 0:
+        raise IanError("ian_box_probe failed (%d)" % rc)
+    return {"tflops": tf.value, "us_per_launch": us.value}
 
 
 def _ptr(buf):

@@ -129,25 +129,79 @@ class NativeRcclComm(Comm):
     """The same data-parallel step with the collective table filled by libian itself from librccl (csrc/ian_comm_rccl.cpp:
     ncclAllReduce on one communicator, ncclAllGather on a second one, on the trainer's streams) -- the route a C caller takes,
     and the default of bench.py / train_cli.py at N > 1.  torch.distributed is used ONLY to hand rank 0's two 128-byte
-    communicator ids to the other ranks and to agree on the outcome: if any rank cannot set the communicators up (no librccl,
-    two ranks on one device, ...) EVERY rank falls back to the torch.distributed filler of the base class, and ``filler`` says so.
+    communicator ids to the other ranks and to agree on the outcome of every set-up stage.
+
+    ``one_comm=True`` (or IAN_RCCL_ONE_COMM=1): no second communicator -- the all-gathers share the gradient communicator, which then
+    serialises everything in issue order.  Slower (a batch-statistics all-gather queues behind the buckets already handed over) but
+    free of the co-residency assumption two communicators on one device make (include/ian_train.h, "CONTRACT"); bench.py falls back to
+    it by itself when the two-communicator step does not come back.
+
+    Set-up is STAGED so that no rank enters a blocking RCCL call unless every rank will: each stage is a local,
+    non-blocking action followed by an agreement over torch.distributed (`_agree`), and only then the collective action all ranks
+    enter together -- librccl loadable on every rank? -> ids from rank 0 -> ncclCommInitRank -> [second communicator] -> preflight
+    buffers allocated? -> preflight collectives -> results right?  If any stage fails on any rank EVERY rank falls back to the
+    torch.distributed filler of the base class together, and ``filler`` says why.  (A rank that dies INSIDE a blocking RCCL call
+    cannot be agreed upon from here: that is what bench.py's per-attempt watchdog is for.)
     One GPU per rank (RCCL refuses two ranks on one device), so the shared-GPU gloo tests cannot drive the native table with two
-    ranks: covered at world size 1 (tests/test_gpu_dp.py), by the fallback agreement test, and by construction."""
+    ranks: covered at world size 1 (tests/test_gpu_dp.py), by the staged-fallback tests (tests/test_comm.py), and by construction."""
 
-    filler = "librccl (native, 2 communicators)"
-
-    def __init__(self, group=None, bucket_bytes=16 << 20):
+    def __init__(self, group=None, bucket_bytes=16 << 20, one_comm=None):
+        import os
         Comm.__init__(self, group, bucket_bytes, gather_group=None)   # a gather GROUP is created only if the fallback needs it
+        self.one_comm = bool(int(os.environ.get("IAN_RCCL_ONE_COMM", "0"))) if one_comm is None else bool(one_comm)
+        self.filler = "librccl (native, %s)" % ("1 communicator" if self.one_comm else "2 communicators")
         self._native_ops = None
+        self.stages = []              # (stage, ok) as agreed by all ranks: what the tests and the bench line can look at
+
+    def _agree(self, stage, ok, why=""):
+        """All ranks learn whether `stage` worked everywhere.  -> (ok everywhere, first reason)."""
+        if self.world > 1:
+            oks = [None] * self.world
+            self.dist.all_gather_object(oks, (bool(ok), str(why)), group=self.group)
+            bad = ["rank %d: %s" % (r, w or "failed") for r, (k, w) in enumerate(oks) if not k]
+            ok, why = (not bad), (bad[0] if bad else "")
+        self.stages.append((stage, bool(ok)))
+        return bool(ok), why
+
+    def _test_fault(self, stage):
+        """IAN_COMM_TEST_FAIL=<stage>[@rank]: the CPU tests inject a failure of one stage on one rank (or all)."""
+        import os
+        spec = os.environ.get("IAN_COMM_TEST_FAIL", "")
+        if not spec:
+            return False
+        st, _, rk = spec.partition("@")
+        return st == stage and (rk == "" or int(rk) == self.rank)
 
     def ops(self, torch, host=False):
         lib = load_train_library()
         err = lambda: (lib.ian_rccl_last_error() or b"?").decode()
+        self.stages = []
+
+        def fallback(why):
+            self.close()
+            if self.world == 1:
+                raise IanTrainError(why or "librccl communicator could not be created")
+            self.filler = "torch.distributed (fallback: %s)" % why
+            # IAN_RCCL_ONE_COMM also applies to the fallback: no second process group either
+            self.gather_group = self.group if self.one_comm else \
+                self.dist.new_group(ranks=self.dist.get_process_group_ranks(self.group) if self.group is not None else None)
+            return Comm.ops(self, torch, host=host)
+
+        # stage 0 -- local, never blocks: can this rank use librccl at all?
+        why = ""
+        if host:
+            why = "host buffers requested"
+        elif self._test_fault("available") or lib.ian_rccl_available() != 0:
+            why = "librccl not loadable: %s" % err()
+        ok, why = self._agree("available", not why, why)
+        if not ok:
+            return fallback(why)
+        # stage 1 -- rank 0 draws the ids (local), everybody receives them (collective on torch.distributed, all ranks enter: agreed above)
         ids, why = None, ""
         if self.rank == 0:
-            bufs = [C.create_string_buffer(128), C.create_string_buffer(128)]
+            bufs = [C.create_string_buffer(128) for _ in range(1 if self.one_comm else 2)]
             rcs = [lib.ian_rccl_unique_id(b) for b in bufs]
-            if any(rcs):
+            if any(rcs) or self._test_fault("ids"):
                 why = "ian_rccl_unique_id failed (%s): %s" % (rcs, err())
             else:
                 ids = [b.raw for b in bufs]
@@ -155,51 +209,60 @@ class NativeRcclComm(Comm):
             box = [ids]
             self.dist.broadcast_object_list(box, src=0, group=self.group)
             ids = box[0]
-        o, ok = CommOps(), False
-        if ids is not None and not host:
-            rc = lib.ian_rccl_comm_create(C.create_string_buffer(ids[0], 128), self.rank, self.world, C.byref(o))
-            if rc:
-                why = "ian_rccl_comm_create failed (%d): %s" % (rc, err())
-            else:
-                self._lib, self._native_ops = lib, o
-                rc = lib.ian_rccl_comm_add_gather(C.byref(o), C.create_string_buffer(ids[1], 128))
-                if rc:
-                    why = "ian_rccl_comm_add_gather failed (%d): %s" % (rc, err())
-                else:
-                    why = self._preflight(torch, o)
-                ok = not why
-        elif host:
-            why = "host buffers requested"
-        if self.world > 1:                         # all ranks take the same route
-            oks = [None] * self.world
-            self.dist.all_gather_object(oks, (bool(ok), why), group=self.group)
-            bad = [w for k, w in oks if not k]
-            if bad:
-                ok, why = False, next((w for w in bad if w), "another rank failed")
-        if ok:
-            self.errors = []
-            return o
-        self.close()
-        if self.world == 1:
-            raise IanTrainError(why or "librccl communicator could not be created")
-        self.filler = "torch.distributed (fallback: %s)" % why
-        self.gather_group = self.dist.new_group(ranks=self.dist.get_process_group_ranks(self.group) if self.group is not None else None)
-        return Comm.ops(self, torch, host=host)
+        ok, why = self._agree("ids", ids is not None, why)
+        if not ok:
+            return fallback(why)
+        # stage 2 -- ncclCommInitRank: every rank enters (blocks until all have)
+        o = CommOps()
+        rc = -99 if self._test_fault("comm_create") else lib.ian_rccl_comm_create(C.create_string_buffer(ids[0], 128), self.rank, self.world, C.byref(o))
+        if rc == 0:
+            self._lib, self._native_ops = lib, o
+        ok, why = self._agree("comm_create", rc == 0, "ian_rccl_comm_create failed (%d): %s" % (rc, err()) if rc else "")
+        if not ok:
+            return fallback(why)
+        # stage 3 -- the all-gathers' own communicator (skipped in one-communicator mode)
+        if not self.one_comm:
+            rc = -99 if self._test_fault("add_gather") else lib.ian_rccl_comm_add_gather(C.byref(o), C.create_string_buffer(ids[1], 128))
+            ok, why = self._agree("add_gather", rc == 0, "ian_rccl_comm_add_gather failed (%d): %s" % (rc, err()) if rc else "")
+            if not ok:
+                return fallback(why)
+        # stage 4 -- preflight: buffers first (local; may fail), agreement, then the collectives all ranks enter, then the verdict
+        pre, why = None, ""
+        try:
+            if self._test_fault("preflight_alloc"):
+                raise RuntimeError("injected")
+            pre = self._preflight_alloc(torch)
+        except BaseException as exc:              # noqa: BLE001 -- every rank must reach the agreement below
+            why = "preflight buffers: %r" % (exc,)
+        ok, why = self._agree("preflight_alloc", pre is not None, why)
+        if not ok:
+            return fallback(why)
+        why = self._preflight_run(torch, o, pre)
+        ok, why = self._agree("preflight", not why, why)
+        if not ok:
+            return fallback(why)
+        self.errors = []
+        return o
 
-    def _preflight(self, torch, o):
+    def _preflight_alloc(self, torch):
+        w, r, n = self.world, self.rank, 1024
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        with torch.cuda.stream(s1):
+            a = torch.full((n,), float(r + 1), device="cuda")
+        with torch.cuda.stream(s2):
+            src = torch.full((n,), float(r + 1), device="cuda")
+            dst = torch.zeros(w * n, device="cuda")
+        torch.cuda.synchronize()
+        return (s1, s2, a, src, dst, n)
+
+    def _preflight_run(self, torch, o, pre):
         """One all-reduce and one all-gather of known values through the freshly filled table, each on its own side stream, before
         the trainer sees it: the local NCCL ABI declarations of csrc/ian_comm_rccl.cpp (datatype / reduction codes, argument
         order) are only exercised with more than one rank here, and a wrong sum must send every rank to the torch.distributed
         filler instead of into the gradients.  Returns "" or the reason."""
         try:
-            w, r, n = self.world, self.rank, 1024
-            s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-            with torch.cuda.stream(s1):
-                a = torch.full((n,), float(r + 1), device="cuda")
-            with torch.cuda.stream(s2):
-                src = torch.full((n,), float(r + 1), device="cuda")
-                dst = torch.zeros(w * n, device="cuda")
-            torch.cuda.synchronize()
+            s1, s2, a, src, dst, n = pre
+            w = self.world
             rcs = (o.allreduce_sum(o.ctx, a.data_ptr(), n, s1.cuda_stream),
                    o.allgather(o.ctx, src.data_ptr(), dst.data_ptr(), n, s2.cuda_stream),
                    o.wait_all(o.ctx, s2.cuda_stream))
@@ -212,7 +275,7 @@ class NativeRcclComm(Comm):
             if not torch.equal(dst, want):
                 return "preflight all-gather returned wrong rows"
             return ""
-        except BaseException as exc:              # noqa: BLE001 -- every rank must reach the agreement below
+        except BaseException as exc:              # noqa: BLE001 -- every rank must reach the agreement
             return "preflight raised %r" % (exc,)
 
     def close(self):
@@ -221,13 +284,28 @@ class NativeRcclComm(Comm):
             self._native_ops = None
 
 
-def default_comm(bucket_bytes=16 << 20):
-    """The communicator bench.py / train_cli.py use: the torch-free RCCL filler when torch.distributed runs on RCCL ("nccl"), the
-    torch.distributed filler otherwise (gloo: CPU rehearsals, ranks sharing one GPU) or when no process group exists."""
+COMM_MODES = ("native2", "native1", "torch")   # bench.py's retry ladder walks them in this order
+
+
+def default_comm(bucket_bytes=16 << 20, mode=None):
+    """The communicator bench.py / train_cli.py use.  mode (argument, else IAN_COMM_MODE, else "native2"):
+        native2  the torch-free RCCL filler with the all-gathers on a second communicator (NativeRcclComm);
+        native1  the same with ONE communicator (also selected by IAN_RCCL_ONE_COMM=1);
+        torch    the torch.distributed filler (one process group per collective kind, or one in all with IAN_RCCL_ONE_COMM=1).
+    The native fillers need torch.distributed on RCCL ("nccl") and more than one rank; otherwise (gloo: CPU rehearsals, ranks
+    sharing one GPU; no process group) the torch.distributed filler is returned whatever the mode."""
+    import os
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == "nccl":
-        return NativeRcclComm(bucket_bytes=bucket_bytes)
-    return Comm(bucket_bytes=bucket_bytes)
+    mode = mode or os.environ.get("IAN_COMM_MODE") or "native2"
+    if mode not in COMM_MODES:
+        raise ValueError("comm mode %r: expected one of %s" % (mode, ", ".join(COMM_MODES)))
+    one = bool(int(os.environ.get("IAN_RCCL_ONE_COMM", "0")))
+    if mode != "torch" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == "nccl":
+        return NativeRcclComm(bucket_bytes=bucket_bytes, one_comm=(mode == "native1") or one)
+    c = Comm(bucket_bytes=bucket_bytes, gather_group=None if one else "own")
+    if one:
+        c.filler = "torch.distributed (one process group)"
+    return c
 
 
 # ======================================================================================================

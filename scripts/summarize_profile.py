@@ -159,14 +159,23 @@ def main():
             md.append("| %s | %d | %.2f | %.2f | %.1f | %s | %s | %s |" % (name, grid, rd / 1e6, wr / 1e6, mf, frac, bc, l2))
             traffic["%s@%d" % (name, grid)] = {"read_bytes": rd, "write_bytes": wr, "mfma_busy_pct": mf, "raw": c}
         out["pmc"] = traffic
-        tg = [(k, v) for k, v in traffic.items() if k.startswith("tapgemm_kernel")]
-        if tg:
-            import math
-            vals = [v["read_bytes"] + v["write_bytes"] for _, v in tg if not math.isnan(v["read_bytes"] + v["write_bytes"])]
-            if vals:
-                out["tapgemm_traffic_bytes_per_launch"] = sum(vals) / len(vals)
-                md += ["", "tapgemm_kernel HBM traffic per launch (mean over the layer shapes above, read x2-corrected + write): **%.1f MB**."
-                       % (out["tapgemm_traffic_bytes_per_launch"] / 1e6), ""]
+        # HBM bytes per tapgemm launch, LAUNCH-WEIGHTED: total bytes of every steady-state tapgemm dispatch / number of such dispatches
+        # (until round 5 this was the unweighted mean over the (kernel name, grid) rows above, which counted a shape launched three
+        # times per step once: 88.4 MB where the launches average 100.6 MB)
+        rd_sum = wr_sum = 0.0
+        rd_n = wr_n = 0
+        for (name, grid), e in per_kernel.items():
+            if not name.startswith("tapgemm_kernel"):
+                continue
+            rd_sum += e["c"].get("FETCH_SIZE", 0) * 1024 * 2
+            rd_n += e["n"].get("FETCH_SIZE", 0)
+            wr_sum += e["c"].get("WRITE_SIZE", 0) * 1024
+            wr_n += e["n"].get("WRITE_SIZE", 0)
+        if rd_n and wr_n:
+            out["tapgemm_traffic_bytes_per_launch"] = rd_sum / rd_n + wr_sum / wr_n
+            out["tapgemm_traffic_weighting"] = "launch-weighted (sum over dispatches / dispatches)"
+            md += ["", "tapgemm_kernel HBM traffic per launch (launch-weighted mean over every steady-state dispatch, read x2-corrected + write): **%.1f MB**."
+                   % (out["tapgemm_traffic_bytes_per_launch"] / 1e6), ""]
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     open(dst + ".md", "w").write("\n".join(md) + "\n")
     # stamp the kernel sources the profile was taken on: bench.py quotes `tapgemm_traffic_bytes_per_launch` as this

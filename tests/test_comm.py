@@ -157,6 +157,107 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 3 and out["dry_run"] is True
 
 
+def _run_bench_dry(extra_env, timeout_s):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    env["IAN_BENCH_BACKEND"] = "gloo"
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--train", "--train-timeout", str(timeout_s),
+                        "--steps", "2", "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+def test_train_leg_ladder_first_mode():
+    """N > 1 training leg of bench.py (round-5 verdict item 4): every attempt runs in child processes with their own rendezvous.  Healthy
+    case: the first collective mode (librccl, two communicators) answers, one attempt, the line says which mode ran."""
+    out = _run_bench_dry({}, 120)
+    t = out["train_step"]
+    assert t["comm_mode"] == "native2" and t["ranks_seen"] == 2 and t["dry_run"] is True
+    assert [a["mode"] for a in t["attempts"]] == ["native2"] and t["attempts"][0]["ok_on_all_ranks"] is True
+
+
+def test_train_leg_ladder_retries_after_a_hang():
+    """A rank that never arrives in a collective (IAN_BENCH_FAKE_HANG: the last rank of the named modes sleeps) must cost ONE attempt, not
+    the run: the children of that attempt are killed at the per-attempt timeout, all parents agree, the next mode is tried -- here the
+    two-communicator mode and the one-communicator mode hang, the torch.distributed filler answers -- and the headline line is intact."""
+    out = _run_bench_dry({"IAN_BENCH_FAKE_HANG": "native2,native1"}, 12)
+    t = out["train_step"]
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2
+    assert t["comm_mode"] == "torch" and t["ranks_seen"] == 2
+    assert [a["mode"] for a in t["attempts"]] == ["native2", "native1", "torch"]
+    assert [a["ok_on_all_ranks"] for a in t["attempts"]] == [False, False, True]
+    assert "timeout" in t["attempts"][0]["outcome_rank0"] and "timeout" in t["attempts"][1]["outcome_rank0"]
+
+
+def test_train_leg_ladder_gives_up_with_the_headline_intact():
+    out = _run_bench_dry({"IAN_BENCH_FAKE_HANG": "native2,native1,torch"}, 8)
+    t = out["train_step"]
+    assert out["n_gpus"] == 2 and "error" in t and len(t["attempts"]) == 3 and not any(a["ok_on_all_ranks"] for a in t["attempts"])
+
+
+def _stage_worker(rank, world, port, q, fail_spec, one_comm):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["IAN_COMM_TEST_FAIL"] = fail_spec
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from neural_photo_editor_amd import trainer as T
+        comm = T.NativeRcclComm(bucket_bytes=1000, one_comm=one_comm)
+        comm.ops(torch, host=False)        # not driven: only the set-up agreement is under test (no GPU here)
+        q.put((rank, comm.filler, list(comm.stages), comm.gather_group is comm.group or comm.gather_group is None))
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("one_comm", [False, True])
+def test_native_comm_setup_is_staged_and_all_ranks_fall_back_together(one_comm):
+    """a rank other than 0 that cannot use librccl must be found out BEFORE anybody enters the blocking
+    ncclCommInitRank.  Rank 1's stage-0 probe is made to fail (IAN_COMM_TEST_FAIL=available@1); both ranks must leave through the
+    torch.distributed filler after the FIRST agreement, with the reason naming rank 1 -- and in one-communicator mode the fallback
+    must not create a second process group either."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stage_worker, args=(r, world, port, q, "available@1", one_comm)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, filler, stages, shared_group in res:
+        assert filler.startswith("torch.distributed (fallback: rank 1:"), filler
+        assert stages == [("available", False)], stages
+        assert shared_group == one_comm
+
+
+def test_default_comm_modes():
+    """trainer.default_comm: mode names are validated, and without an RCCL process group every mode is the torch.distributed filler;
+    IAN_RCCL_ONE_COMM=1 removes the second process group of the torch filler as well."""
+    from neural_photo_editor_amd import trainer as T
+    assert T.COMM_MODES == ("native2", "native1", "torch")
+    for m in T.COMM_MODES:
+        assert type(T.default_comm(mode=m)) is T.Comm
+    with pytest.raises(ValueError):
+        T.default_comm(mode="nccl3")
+    os.environ["IAN_RCCL_ONE_COMM"] = "1"
+    try:
+        c = T.default_comm()
+        assert c.gather_group is None and "one process group" in c.filler
+        assert T.NativeRcclComm().one_comm is True
+    finally:
+        del os.environ["IAN_RCCL_ONE_COMM"]
+    assert T.NativeRcclComm().one_comm is False and T.NativeRcclComm(one_comm=True).filler == "librccl (native, 1 communicator)"
+
+
 def test_local_rccl_abi_declarations_match_the_installed_header():
     """csrc/ian_comm_rccl.cpp declares the slice of the NCCL ABI it calls itself (no rccl.h at build time) and
     resolves the entry points with dlopen; with more than one rank those declarations run for the first time on the 8-GPU node, so

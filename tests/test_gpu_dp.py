@@ -16,9 +16,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import dp_rehearsal  # noqa: E402  (tests/dp_rehearsal.py: the worker, shared with scripts/exp/config5_rehearsal.py)
 
 
-# (world, global batch): the round-1..4 case, and a world-4 x 32 images version of BASELINE.json configs[4] (8 x 128 = 1024 runs as
-# scripts/exp/config5_rehearsal.py -> profiles/r05_config5_rehearsal.json: ~4 GPU-minutes, outside the suite's budget)
-@pytest.mark.parametrize("world,B", [(2, 4), (4, 128)])
+# (world, global batch): the round-1..4 case, and BASELINE.json configs[4]'s WORLD SIZE at 16 images per rank (global 128): the 8-way
+# rank-ordered tree of the batch statistics, the MinibatchLayer over all 8 shards and the multi-bucket plans are driver-run (round 5 ran
+# 4 x 32 here).  The real shape, 8 x 128 = 1024, stays a committed record: scripts/exp/config5_rehearsal.py ->
+# profiles/r05_config5_rehearsal.json (~4 GPU-minutes, outside the suite's budget)
+@pytest.mark.parametrize("world,B", [(2, 4), (8, 128)])
 def test_sharded_step_equals_single_process_step(world, B, tmp_path, monkeypatch):
     # Split-K schedules are a function of the per-rank batch: with them on, the same image's activations differ in the last bit
     # between the two runs and a handful of leaky-ReLU branches flip (measured: up to 5e-4 on a few tensors).  The collectives are
@@ -65,8 +67,10 @@ def test_batch_statistics_are_bitwise_rank_order_invariant():
         assert np.allclose(got[C:], (ref ** 2).sum(0), rtol=1e-13, atol=0)
 
 
-def test_native_rccl_collective_table_single_rank():
-    """csrc/ian_comm_rccl.cpp: the ian_comm_ops table filled from librccl itself (dlopen), exercised as far as ONE GPU allows: a
+@pytest.mark.parametrize("one_comm", [False, True])
+def test_native_rccl_collective_table_single_rank(one_comm):
+    """(one_comm: the IAN_RCCL_ONE_COMM=1 mode -- the all-gathers share the gradient communicator -- must behave the same.)
+    csrc/ian_comm_rccl.cpp: the ian_comm_ops table filled from librccl itself (dlopen), exercised as far as ONE GPU allows: a
     1-rank pair of communicators (all-reduce; all-gather on its own one) whose collectives are identities on the trainer's kind of
     buffers and streams; wait_all orders the compute stream behind EVERY side stream an all-reduce was issued on since the last
     wait (round 4 recorded the last one only), and the table is accepted by ian_trainer_set_comm.
@@ -74,9 +78,11 @@ def test_native_rccl_collective_table_single_rank():
     import ctypes as C
     import torch
     from neural_photo_editor_amd import trainer as T
-    comm = T.NativeRcclComm()
+    comm = T.NativeRcclComm(one_comm=one_comm)
     assert comm.world == 1
-    ops = comm.ops(torch)                                      # comm_create + add_gather
+    ops = comm.ops(torch)                                      # comm_create [+ add_gather] + preflight, every stage agreed
+    assert [k for k, _ in comm.stages] == ["available", "ids", "comm_create"] + ([] if one_comm else ["add_gather"]) + ["preflight_alloc", "preflight"]
+    assert all(ok for _, ok in comm.stages) and (("1 communicator" in comm.filler) == one_comm)
     try:
         assert (ops.world, ops.rank) == (1, 0) and ops.ctx and comm.filler.startswith("librccl")
         side_a, side_b, main = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()
@@ -103,7 +109,8 @@ def test_native_rccl_collective_table_single_rank():
         assert torch.equal(dst, wx + 1)
         assert ops.allreduce_sum(ops.ctx, 0, 16, 0) != 0                                           # null buffer: an error code, no crash
         lib = comm._lib
-        assert lib.ian_rccl_comm_add_gather(C.byref(ops), C.create_string_buffer(128)) == -6       # a second gather communicator: refused
+        if not one_comm:
+            assert lib.ian_rccl_comm_add_gather(C.byref(ops), C.create_string_buffer(128)) == -6   # a second gather communicator: refused
     finally:
         comm.close()
     assert ops.ctx is None
