@@ -585,13 +585,13 @@ def main(argv=None):
         (+-7 % seen for one commit) become comparable through `whole_step_frac_of_sustained`."""
         from neural_photo_editor_amd import lib as L
         try:
-            a = L.box_probe(1600, 250, stream=stream)
-            b = L.box_probe(6400, 70, stream=stream)
+            a = L.box_probe(900, 250, stream=stream)       # ~200 us per launch
+            b = L.box_probe(3200, 70, stream=stream)       # ~700 us per launch
             return {"sustained_f32_mfma_tflops": a["tflops"], "launch_us": a["us_per_launch"],
                     "sustained_f32_mfma_tflops_long_launches": b["tflops"], "long_launch_us": b["us_per_launch"],
                     "frac_of_spec_peak": a["tflops"] / FP32_MFMA_PEAK_TFLOPS,
                     "how": "ian_box_probe: v_mfma_f32_32x32x2_f32 back to back from registers, 2 x 4 waves per CU, non-zero operands, no memory "
-                           "traffic; 250 launches of 1600 x 4 MFMAs per wave (the launch length of one IAN_simple batch-64 layer) and 70 of 6400 x 4"}
+                           "traffic; 250 launches of 900 x 4 MFMAs per wave (~200 us: the launch length of one IAN_simple batch-64 layer) and 70 of 3200 x 4 (~700 us)"}
         except Exception as exc:
             return {"error": "%s: %s" % (type(exc).__name__, exc)}
 
@@ -657,6 +657,40 @@ def main(argv=None):
                     t = time.perf_counter()
                     z = model.brush_step(c1, r1, c2, r2, z, RGB=rgb, weight=0.05, image=False, photo=(RECON, ERROR))[0]
                     lat6.append((time.perf_counter() - t) * 1e3)
+                # the C caller's view of one event ("interactive entry"): bare ian_brush_step through ctypes on preallocated
+                # buffers, with and without the 48 KB float image copied out (a UI takes the uint8 image: ian_decode_u8 / photo args)
+                import ctypes as C
+                zin, zout, ximg = np.ascontiguousarray(z[:1]), np.empty((1, 100), np.float32), np.empty((1, 3, 64, 64), np.float32)
+                pz, pzo, px, prgb, null = [C.c_void_p(v.ctypes.data) for v in (zin, zout, ximg, rgb)] + [C.c_void_p(0)]
+                fn, hh = h.lib.ian_brush_step, h._h
+
+                def c_caller(img, n=160, skip=40):
+                    ts = []
+                    for _ in range(n):
+                        t = time.perf_counter()
+                        rc = fn(hh, c1, r1, c2, r2, prgb, pz, -0.05, float(1 + (c2 - c1)), pzo, null, px if img else null, None, null)
+                        ts.append((time.perf_counter() - t) * 1e3)
+                        assert rc == 0
+                        zin[:] = zout
+                    return float(np.percentile(ts[skip:], 50))
+                c_img, c_noimg = c_caller(True), c_caller(False)
+                # EXPERIMENT (round-5 verdict item 5a): a one-wave keep-warm kernel holds the interactive queue busy until the next event
+                keep_warm = None
+                try:
+                    h.set_option("edit_keep_warm_us", 400)
+                    kw = c_caller(False, n=200, skip=60)
+                    h.set_option("edit_keep_warm_us", 0)
+                    again = c_caller(False, n=200, skip=60)
+                    keep_warm = {"p50_ms_c_caller_keep_warm_400us": kw, "p50_ms_c_caller_without_in_the_same_loop": again,
+                                 "what": "option edit_keep_warm_us (off by default): after each event one wave spins on a flag in the mapped "
+                                         "pinned block for up to 400 us; the next event releases it and launches its graph behind it"}
+                except Exception as exc:
+                    keep_warm = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                    try:
+                        h.set_option("edit_keep_warm_us", 0)
+                    except Exception:
+                        pass
+                z = zin.copy()
                 # BASELINE.json configs[3] words it as an "Adam edit loop" (the reference brush is plain gradient
                 # descent; Adam only exists in training): the same 100-step loop with an Adam update of the latent on the host
                 za, ma, va, lat7 = z.copy(), np.zeros_like(z), np.zeros_like(z), []
@@ -683,6 +717,7 @@ def main(argv=None):
                         "p50_ms_photo_mode": float(np.percentile(lat3[20:], 50)),
                         "p50_ms_one_call": float(np.percentile(lat5[20:], 50)), "p95_ms_one_call": float(np.percentile(lat5[20:], 95)),
                         "p50_ms_one_call_photo_mode": float(np.percentile(lat6[20:], 50)),
+                        "p50_ms_c_caller": c_noimg, "p50_ms_c_caller_with_float_image": c_img, "keep_warm": keep_warm,
                         "update": "gradient descent (reference, NPE.py:199-209)",
                         "adam_variant": {"p50_ms": float(np.percentile(lat7[20:], 50)), "p95_ms": float(np.percentile(lat7[20:], 95)), "steps": 100,
                                          "update": "Adam(lr 0.01, 0.9, 0.999) on the host between imgradRGB and sample_at (two calls per step)"},

@@ -192,7 +192,7 @@ int ian_set_option(ian_handle* h, const char* key, int32_t value);
    from different boxes comparable).  Runs `launches` back-to-back launches of a register-only v_mfma_f32_32x32x2_f32 loop of
    `iters` x 4 MFMAs per wave (2 workgroups of 4 waves on each of the 256 CUs, non-zero operands, no memory traffic) on the
    current device's `stream` and returns the sustained fp32 matrix rate in TFLOP/s and the mean launch duration in microseconds.
-   iters = 1600 gives launches of ~200 us (one IAN_simple batch-64 layer), 6400 ~700 us.  Needs no handle.  0 = ok, <0 = HIP error. */
+   iters = 900 gives launches of ~200 us (one IAN_simple batch-64 layer), 3200 ~700 us.  Needs no handle.  0 = ok, <0 = HIP error. */
 int ian_box_probe(int32_t iters, int32_t launches, double* tflops, double* us_per_launch, void* stream);
 
 const char* ian_last_error(ian_handle* h);

@@ -88,6 +88,8 @@ struct TgParams {
   float* raw;                 // fused == 2: one zero-at-rest accumulation tile per output tile (float atomics)
   int fused;                  // 0: slabs + a tapgemm_reduce launch; 1: write-through slabs combined by the tile's last arriver;
                               // 2: atomic accumulation into `raw`, epilogue by the last arriver (kernels_tapgemm.hip)
+  const unsigned short* wsplit;  // tapgemm_bf16x3_kernel: the weights pre-split into a bf16 hi plane followed by a lo plane (or nullptr)
+  int bf_sched;                  // ... and its K-loop schedule (0..2)
 };
 
 struct TgReduceParams {
@@ -99,6 +101,7 @@ struct TgReduceParams {
   int M, qw_shift, qhw_shift, so, OH, OW, Cout, y_stride;
 };
 
+constexpr int TG_VARIANT_BF16X3 = 5;   // TgParams::variant of tapgemm_bf16x3_kernel (opt-in, ian_set_option("tg_bf16x3", 1))
 enum TgConfig { TG_128x128 = 0, TG_128x64 = 1, TG_64x64 = 2, TG_32x128 = 3, TG_256x128 = 4, TG_128x32 = 5,
                 TG_128x128W8 = 6 /* 128x128 tile, 8 waves of 64x32 */, TG_128x64W8 = 7 /* 128x64 tile, 8 waves of 32x32 */,
                 TG_NCONFIG = 8 };
@@ -126,6 +129,11 @@ static inline bool tg_fuse_supported(int cfg) {
   return false;
 #endif
   return cfg == TG_32x128 || cfg == TG_64x64 || cfg == TG_128x64 || cfg == TG_128x32;
+}
+
+// tile configurations tapgemm_bf16x3_kernel is instantiated for (its staging pass covers 16 x waves rows: 4 threads per row)
+static inline bool tg_bf16x3_supported(int cfg) {
+  return cfg == TG_128x128 || cfg == TG_128x64 || cfg == TG_64x64 || cfg == TG_128x128W8;   // 256x128 compiles too but spills (1152 B of scratch)
 }
 
 // launches that can carry the GEMM-epilogue batch statistics (TgStats): a separate kernel instantiation exists for the
@@ -164,6 +172,8 @@ struct B1Params {
 hipError_t launch_b1conv(const B1Params& p, int mode, hipStream_t s);
 
 hipError_t launch_tapgemm(int cfg, const TgParams& p, int nitems, hipStream_t s);
+// fp32 weights -> bf16 hi plane | lo plane (2 n values) for tapgemm_bf16x3_kernel
+hipError_t launch_wsplit(const float* w, unsigned short* out, long long n, hipStream_t s);
 // ian_box_probe: register-only fp32-MFMA loop, `blocks` workgroups of 256 threads, 4 x iters MFMAs per wave (kernels_misc.hip)
 hipError_t launch_box_probe(const float* in, float* out, int blocks, int iters, hipStream_t s);
 // kp > 1: four lanes share the slabs of one output element (few tiles, many slabs: batch 1)
@@ -308,6 +318,7 @@ struct PhotoBlendArgs {
 };
 hipError_t launch_photo_blend(const PhotoBlendArgs& a, hipStream_t s);
 hipError_t launch_latent_update(float* z, const float* g, const float* cg, int n, float* z_mirror, float* g_mirror, hipStream_t s);
+hipError_t launch_keep_warm(const int* flag, long long max_ticks, hipStream_t s);   // experiment: see kernels_npe.hip
 hipError_t launch_to_uint8(const float* x, unsigned char* y, long long n, hipStream_t s);
 
 // identity-edge gradient hand-over: gd[p,c] (+)= gs[p,coff+c] * act'(y[p,c]) * scale[c]   (NHWC, strides ss / ds)

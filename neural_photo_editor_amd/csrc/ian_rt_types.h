@@ -30,6 +30,7 @@ struct Schedule {
   int* d_counters = nullptr;   // split-K combine fused into the tapgemm launch: one arrival counter per tile (zero at rest)
   float* d_raw = nullptr;      // fused == 2: one accumulation tile per output tile (zero at rest)
   int fused = 0;               // how this schedule's split-K partials are combined (TgParams::fused)
+  bool bf16x3 = false;         // launches go to tapgemm_bf16x3_kernel (option tg_bf16x3 and a tile it is instantiated for)
   size_t slab_tiles = 0;
   int max_nsplit = 1;
   std::vector<TgItem> h_items;  // kept for tests / debugging
@@ -53,6 +54,8 @@ struct TgLayer {
   std::vector<float> h_w;  // packed weights (freed after upload)
   size_t w_floats = 0;
   float* d_w = nullptr;
+  unsigned short* d_wsplit = nullptr;   // d_w split into a bf16 hi plane + lo plane (2 x w_floats values) for tapgemm_bf16x3_kernel; made lazily
+  bool wsplit_valid = false;            // ... and re-made after d_w changed (training layers repack their slabs after every update)
   TgClass* d_classes = nullptr;
   TgTap* d_taps = nullptr;
   std::map<int, Schedule> sched;  // per batch size
@@ -114,6 +117,18 @@ struct Options {
   int tg_fuse_tune = 0;              // fused modes ian_autotune may try for such launches: 0 none, 1 = mode 1, 2 = modes 1 and 2.  OFF: measured on
                                      // MI355X (profiles/r05_b1_inlaunch_combine_ab.json) the autotuner kept the reduce launch for every 5x5 layer, and
                                      // the fused modes forced on untuned layers cost +13 us (mode 1) / +9 us (mode 2) per layer
+  int tg_bf16x3 = 0;                 // OPT-IN, never the default: tap-GEMMs with at least tg_bf16x3_min_m rows on the bf16 matrix cores, every fp32
+                                     // product as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi of split-bf16 operands with fp32 accumulation (kernels_tapgemm.hip
+                                     // tapgemm_bf16x3_kernel): ~1e-5 relative error instead of exact fp32 -- inside the 1e-4 parity bar, but a different
+                                     // arithmetic type, so bench.py reports it as a labelled secondary only
+  int tg_bf16x3_min_m = 256;
+  int tg_bf16x3_min_images = 2;      // ... and never to batch-1 launches: the interactive chains are latency-bound (no use for matrix rate), and the
+                                     // brush GRADIENT is discontinuous in the forward activations (ReLU / leaky-ReLU kinks): measured, a 1e-5 forward
+                                     // error flips a unit under the patch and moves dL/dz by 1e-3 on 2 of the 6 fixture patches, while split-bf16
+                                     // backward-data alone stays within 1.1e-5 (scripts/exp/bf16x3_brush_debug.py)
+  int tg_bf16x3_wsplit = 1;          // weights pre-split once per layer (0: split at staging like the activations)
+  int tg_bf16x3_sched = 1;           // K-loop schedule of tapgemm_bf16x3_kernel (0..2, kernels_tapgemm.hip)
+  int tg_bf16x3_fwd = 1, tg_bf16x3_bwd = 1;   // which epilogue modes (forward / backward-data launches) the option applies to
   int tg_reduce_kp = 4;              // split-K reduce: lanes sharing one output element's slabs when a tile has >= 8 slabs
   int wg_w8 = 1;                     // tapwgrad: 8-wave 128x128 workgroups (16 waves per CU instead of 8)
   int wg_xcd_split = 1;              // tapwgrad: all items of one pixel range go to one XCD (its rows are fetched into that L2 once), split count a
@@ -131,6 +146,8 @@ struct Options {
   int fuse_latent_update = 1;        // ian_brush_step: the latent update rides in the epilogue of the latent's backward GEMV (round 5)
   int edit_graph = 1;                // batch-1 host-pointer calls (the NPE edit loop) replay captured hipGraphs
   int edit_spin = 1;                 // ... and their final wait polls the stream (hipStreamQuery) before it falls back to hipStreamSynchronize
+  int edit_keep_warm_us = 0;         // EXPERIMENT (off): after a brush event a one-wave kernel keeps the interactive stream's queue busy for up to
+                                     // this many microseconds, released by the next call (kernels_npe.hip keep_warm_kernel)
   int edit_zero_copy = 1;            // their kernels read the brush rectangle from / write z, dz, the image to the pinned block directly
   int head_fused = 1;                // RGB-Beta head as head6 + head_tail (kernels_head.hip) when the graph matches IAN.py:183-207
   int head_fused_min_n = 8;          // ... for batches of at least this many images (the latent brush's batch-1 backward
@@ -218,6 +235,7 @@ struct ian_handle {
   // set around run_decoder_backward by ian_brush_step: the latent's backward GEMV also applies Z += coef * (dZ * gscale) (one launch
   // less per brush event); done = the fused form was taken (else the caller launches latent_update_kernel)
   struct { const float* cg = nullptr; float* z_mirror = nullptr; float* g_mirror = nullptr; bool done = false; } upd;
+  bool warm_armed = false;       // a keep_warm_kernel is (or may still be) spinning on edit_stream: enter_stream releases it
   bool pin_img_valid = false;    // pin[PIN_IMG..] holds the image that is resident in the output slot
   int* d_patch = nullptr;
   EditGraph g_fwd, g_bwd[2], g_step[2][2];   // g_step[mode][image wanted]: backward + latent update + forward (ian_brush_step)

@@ -148,6 +148,7 @@ struct ian_trainer {
   // is final at that point and is not written again in the same sweep) and overlap the element-wise kernels of the
   // backward-data chain; the compute stream joins before the regularisers.  Same launches, same per-parameter order.
   int overlap_wgrad = 1;
+  int wgrad_priority = 0;                           // weight-gradient stream created with the lowest stream priority (make_wgrad_stream)
   hipStream_t st2 = nullptr;
   std::vector<hipEvent_t> events;
   size_t ev_used = 0;
@@ -759,6 +760,34 @@ int bn_backward_finish(ian_trainer* t, BN& bn, const float* dA, const float* a, 
   TK(ian_k_bn_bwd(dA, a, y, bn.mean, bn.inv_std, bn.scale, bn.bsums, bn.count, dy, rows, C, stride, act, t->st));
   return 0;
 }
+// The weight-gradient stream.  wgrad_priority = 1: created with the LOWEST stream priority the device offers, so that the dispatcher
+// prefers the compute stream's workgroups whenever both streams have some ready: a data-path GEMM then keeps the whole chip, and
+// the weight-gradient GEMMs -- which nothing downstream reads before the optimiser -- queue up and fill the chip while the
+// compute stream runs its HBM-bound element-wise passes (batch-statistics sums, batch-norm backward, head gathers) instead of
+// being consumed earlier at half rate next to a data-path GEMM (profiles/r05_train_ian_b128.md: the second stream was busy 82 of
+// the 200 ms four updates span, the matrix pipe idle during most element-wise passes).  Same launches, same operands, same
+// stream-order dependencies: bitwise the unprioritised step.
+int make_wgrad_stream(ian_trainer* t) {
+  if (t->st2) {
+    (void)hipStreamSynchronize(t->st2);
+    (void)hipStreamDestroy(t->st2);
+    t->st2 = nullptr;
+  }
+  hipError_t e;
+  if (t->wgrad_priority) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);      // numerically: least >= greatest (lower number = higher priority)
+    e = hipStreamCreateWithPriority(&t->st2, hipStreamNonBlocking, least);
+  } else {
+    e = hipStreamCreateWithFlags(&t->st2, hipStreamNonBlocking);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    t->st2 = nullptr;
+    return 1;
+  }
+  return 0;
+}
 int side_stream(ian_trainer* t, hipStream_t* out) {  // the stream a weight-gradient launch goes to, ordered behind what is on t->st now
   *out = t->st;
   if (!t->overlap_wgrad || !t->st2) return 0;
@@ -1341,10 +1370,8 @@ int ian_trainer_finalize(ian_trainer* t) {
   t->zgen = dalloc(t, (size_t)t->n * 128); t->zgen0 = dalloc(t, (size_t)t->n * 128);
   t->xin = dalloc(t, (size_t)t->n * 3 * 4096); t->zin = dalloc(t, (size_t)t->n * 100); t->epsin = dalloc(t, (size_t)t->n * 100);
   if (t->oom) return tfail(t, -20, "out of device memory while allocating the training step's buffers (batch %d per GPU)", t->n);
-  if (hipStreamCreateWithFlags(&t->st2, hipStreamNonBlocking) != hipSuccess) {
-    (void)hipGetLastError();
-    t->st2 = nullptr;   // no second stream: weight gradients stay on the compute stream
-  }
+  if (const char* e = getenv("IAN_WGRAD_PRIORITY")) t->wgrad_priority = atoi(e);
+  if (make_wgrad_stream(t) != 0) t->st2 = nullptr;   // no second stream: weight gradients stay on the compute stream
   if (t->world > 1) THIP(hipStreamCreateWithFlags(&t->st_comm, hipStreamNonBlocking));
   if (t->exact && ((t->n & (t->n - 1)) || (t->world & (t->world - 1))))
     fprintf(stderr, "libian: per-rank batch %d x world %d is not a power of two: the partial-sum tree of the batch statistics associates "
@@ -1675,6 +1702,11 @@ int ian_trainer_set_option(ian_trainer* t, const char* key, double value) {
   if (k == "learning_rate") t->cfg.learning_rate = value;  // train_IAN.py:523-527 learning-rate schedule
   else if (k == "head6") t->head6 = value != 0.0;
   else if (k == "overlap_wgrad") t->overlap_wgrad = value != 0.0;
+  else if (k == "wgrad_priority") {      // 0: default-priority weight-gradient stream, 1: lowest priority (see make_wgrad_stream)
+    (void)hipDeviceSynchronize();
+    t->wgrad_priority = value != 0.0;
+    if (t->finalized) (void)make_wgrad_stream(t);
+  }
   else if (k == "update_running") t->update_running = value != 0.0;
   else if (k == "fused_stats") t->fused_stats = value != 0.0;                 // GEMM-epilogue batch statistics (single-process step)
   else if (k == "overlap") t->overlap = value != 0.0;                       // gradient buckets handed over during backward

@@ -143,4 +143,20 @@ hipError_t launch_to_uint8(const float* x, unsigned char* y, long long n, hipStr
   return hipGetLastError();
 }
 
+
+// ---- keep-warm (option edit_keep_warm_us, an EXPERIMENT, off by default) ---------------------------------------------------------
+// One wave that keeps the interactive stream's queue busy between two brush events: it polls a flag in the mapped pinned block
+// (the next event sets it just before its graph is launched) and gives up after max_ticks of the 100 MHz wall clock (s_memrealtime).  What it is for:
+// the first kernel of every graph replay costs ~20 us whatever it does (profiles/r05_batch1_chains.md) -- is that the wake-up of
+// an idle queue?  The bench line's edit_step.keep_warm compares the event latency with and without it.
+__global__ __launch_bounds__(64) void keep_warm_kernel(const volatile int* flag, long long max_ticks) {
+  if (threadIdx.x != 0) return;
+  const long long t0 = (long long)wall_clock64();
+  while (*flag == 0 && (long long)wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(8);
+}
+hipError_t launch_keep_warm(const int* flag, long long max_ticks, hipStream_t s) {
+  hipLaunchKernelGGL(keep_warm_kernel, dim3(1), dim3(64), 0, s, flag, max_ticks);
+  return hipGetLastError();
+}
+
 }  // namespace ian

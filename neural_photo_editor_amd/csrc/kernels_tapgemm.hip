@@ -727,6 +727,370 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
   tg_store<BM, BN, WM, WN>(p, it, cl, acc, wm, wn, lane);
 }
 
+// =====================================================================================================================
+// tapgemm_bf16x3_kernel -- OPT-IN variant (ian_set_option("tg_bf16x3", 1); never the default, never the headline `value`):
+// the same implicit GEMM over the same item / tap tables, with every fp32 operand split into two bf16 halves at staging time
+// (x = hi + lo, hi = RNE bf16(x), lo = RNE bf16(x - hi): 16 significant bits) and each product evaluated as
+//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (the a_lo*b_lo term, 2^-18 relative, is dropped)
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 3 x 32 cycles per 32x32x16 block where v_mfma_f32_32x32x2_f32 needs
+// 8 x 64 -- 5.3x the matrix rate at ~1e-5 relative error, inside the north star's 1e-4 tolerance but NOT exact fp32 (ruling of
+// the round-3 / round-5 verdicts: a labelled secondary).  gfx950 specifics:
+//   * the activations and weights stay fp32 in HBM (same buffers, same buffer-descriptor zero fill for halo / ragged rows);
+//     a thread stages 8 consecutive channels of one row per pass (2 dwordx4 loads), splits them with 6 VALU per pair
+//     (v_cvt_pk_bf16_f32, shift / mask, 2 subtractions, v_cvt_pk_bf16_f32) in the shadow of the MFMAs and writes ONE
+//     ds_write_b128 into the hi plane and one into the lo plane;
+//   * LDS planes are [row][32 bf16 + 8 pad] = 80-byte rows: 20 banks per row -> the 16 rows of a ds_read_b128 service group
+//     fall on 16 distinct 4-bank groups (conflict free); a lane's fragment for one k16 step is ONE ds_read_b128 (8 bf16);
+//   * a K-step (one tap x 32 channels) is 2 k16 steps x 3 MFMAs per 32x32 block = 768 MFMA cycles for a 64x64 wave tile, a fifth
+//     of the fp32 K-step: one tile of prefetch no longer covers an L2 miss, so the loads of TWO K-steps are in flight
+//     (register queue, as VAR 4);
+//   * wave tiles are 64x64 wherever the tile allows (4 waves on 128x128): a 64x32 wave tile would need 125 B/clk/CU of LDS reads.
+// Epilogue, split-K slabs and the reduce launch are the fp32 kernel's.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int TGB_ROWB = 80;   // bytes per LDS row of one plane (32 bf16 + 8 pad)
+
+// two floats -> packed bf16 pair of their high halves and of the residuals
+__device__ __forceinline__ void tgb_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const f32x2 v = {x0, x1};
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);          // v_cvt_pk_bf16_f32 (round to nearest even)
+  hi = __builtin_bit_cast(unsigned, h);
+  const float r0 = x0 - __uint_as_float(hi << 16);
+  const float r1 = x1 - __uint_as_float(hi & 0xFFFF0000u);
+  const f32x2 r = {r0, r1};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+__device__ __forceinline__ void tgb_split8(const float4& a, const float4& b, u32x4& hi, u32x4& lo) {
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  tgb_split2(a.x, a.y, h0, l0);
+  tgb_split2(a.z, a.w, h1, l1);
+  tgb_split2(b.x, b.y, h2, l2);
+  tgb_split2(b.z, b.w, h3, l3);
+  hi = u32x4{h0, h1, h2, h3};
+  lo = u32x4{l0, l1, l2, l3};
+}
+
+// BSPLIT: the weights arrive PRE-SPLIT (TgParams::wsplit: hi plane then lo plane, bf16, the fp32 slabs' indexing; made once per layer by
+//         wsplit_kernel) -- half the split VALU work and no fp32 weight registers;  false: weights split at staging like the activations.
+// SCHED:  0 = store(next tile) -> loads -> compute, compiler-scheduled inside each phase;
+//         1 = loads pinned at the top, then the two k16 groups of MFMAs with the split / store work of the next tile placed between
+//             them in source order, scheduler free;
+//         2 = as 1 with sched_group_barrier pipelines: one MFMA, then a few VALU / LDS instructions of the next tile, repeated.
+template <int BM, int BN, int WM, int WN, bool BSPLIT, int SCHED>
+__global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_bf16x3_kernel(const TgParams p) {
+  constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
+  constexpr int NT = 64 * WM * WN, RS = NT / 4;          // a staging pass covers RS rows: 4 threads x 8 channels per row
+  constexpr int A_CH = BM / RS, B_CH = BN / RS;
+  static_assert(BM % RS == 0 && BN % RS == 0, "tile rows must be a multiple of the staging pass");
+  constexpr int PLANE_A = BM * TGB_ROWB, PLANE_B = BN * TGB_ROWB, BUF = 2 * (PLANE_A + PLANE_B);   // bytes
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* lds = reinterpret_cast<char*>(smem);              // [2][A_hi | A_lo | B_hi | B_lo]
+
+  const TgItem it = p.items[blockIdx.x];
+  if (it.ks0 >= it.ks1) return;  // padding item
+  const TgClass cl = p.classes[it.cls];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  // B operand: fp32 slabs (split here) or the pre-split planes (same element indexing, 2 bytes per element, lo plane w_bytes / 2 further)
+  const __amdgpu_buffer_rsrc_t wrsrc = BSPLIT
+      ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.wsplit), 0, p.w_bytes, 0x00020000)
+      : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+  constexpr int WB = BSPLIT ? 2 : 4;                      // bytes per weight element in the buffer addressed
+  const unsigned w_cls = (unsigned)(cl.w_off * WB);
+  const unsigned w_lo = p.w_bytes / 2;                    // BSPLIT: byte offset of the lo plane
+
+  // staging rows: a ds_write_b128 is serviced in groups of 16 lanes = 4 rows x 4 chunks of 16 bytes; with 80-byte rows the four rows of
+  // a group must be 4 apart (bank offsets 0 / 16 / 32 / 48 of 64) to be conflict free -- consecutive rows wrap onto each other (measured:
+  // SQ_LDS_BANK_CONFLICT 29-33 % of the LDS cycles with r0 = tid >> 2).  So the two 2-bit fields of the row index are swapped.
+  const int q0 = tid >> 2;
+  const int r0 = (q0 & ~15) | ((q0 & 3) << 2) | ((q0 >> 2) & 3);
+  const int c8 = (tid & 3) * 8;
+  int a_iy0[A_CH], a_ix0[A_CH];
+  unsigned a_off[A_CH];
+  const int qhw_mask = (1 << p.qhw_shift) - 1, qw_mask = (1 << p.qw_shift) - 1;
+#pragma unroll
+  for (int j = 0; j < A_CH; ++j) {
+    const int m = it.m0 + r0 + RS * j;
+    const int n = m >> p.qhw_shift;
+    const int rem = m & qhw_mask;
+    const int qy = rem >> p.qw_shift, qx = rem & qw_mask;
+    const int iy0 = qy * p.si + p.by, ix0 = qx * p.si + p.bx;
+    a_iy0[j] = (m < p.M) ? iy0 : -100000;
+    a_ix0[j] = ix0;
+    a_off[j] = (unsigned)((((n * p.IH + iy0) * p.IW + ix0) * p.Cin + c8) * 4);
+  }
+  const int kpt = p.Cin >> 5;
+  const unsigned slab_bytes = (unsigned)p.CoutPad * (unsigned)p.Cin * (unsigned)WB;
+  const unsigned w_row = (unsigned)(((it.n0 + r0) * p.Cin + c8) * WB);
+  const unsigned w_rstep = (unsigned)(RS * p.Cin * WB);
+  int tap = it.ks0 / kpt;
+  int cstep = it.ks0 - tap * kpt;
+  const int nks = it.ks1 - it.ks0;
+  const int last_tap = cl.ntaps - 1;
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // One K-step of operands in registers: A as 2 x float4 per pass (fp32, split at store time); B as (hi, lo) 16-byte vectors per pass
+  // when pre-split, else 2 x float4 like A.  Loads are BRANCH-FREE: a K-step beyond the item's range (`live` false) addresses out
+  // of range and the hardware returns zeros, so that a whole loop body is one basic block the scheduler can pipeline.
+  struct Regs {
+    float4 a[2 * A_CH];
+    float4 b[2 * B_CH];   // BSPLIT: b[2j] = hi bits, b[2j+1] = lo bits (as raw 16-byte vectors)
+  };
+  auto load_into = [&](Regs& R, bool live) {
+    const TgTap tp = p.taps[cl.tap0 + min(tap, last_tap)];
+    const unsigned doff = (unsigned)(((tp.dy * p.IW + tp.dx) * p.Cin + (cstep << 5)) * 4);
+#pragma unroll
+    for (int j = 0; j < A_CH; ++j) {
+      const int iy = a_iy0[j] + tp.dy, ix = a_ix0[j] + tp.dx;
+      const bool ok = live & ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);
+      const unsigned o = ok ? a_off[j] + doff : 0xFFFFFFE0u;
+      R.a[2 * j] = buf_load4(xrsrc, o, 0);
+      R.a[2 * j + 1] = buf_load4(xrsrc, o, 16);
+    }
+    const unsigned wsoff = w_cls + (unsigned)tap * slab_bytes + (unsigned)(cstep << 5) * WB;
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) {
+      const unsigned o = live ? w_row + j * w_rstep : 0xFFFFFFE0u;
+      if (BSPLIT) {
+        R.b[2 * j] = buf_load4(wrsrc, o, wsoff);
+        R.b[2 * j + 1] = buf_load4(wrsrc, o, live ? wsoff + w_lo : 0);
+      } else {
+        R.b[2 * j] = buf_load4(wrsrc, o, wsoff);
+        R.b[2 * j + 1] = buf_load4(wrsrc, o, wsoff + 16);
+      }
+    }
+    if (++cstep == kpt) {
+      cstep = 0;
+      ++tap;
+    }
+  };
+  auto store_a = [&](const Regs& R, int buf) {
+    char* a_ = lds + buf * BUF + r0 * TGB_ROWB + c8 * 2;
+#pragma unroll
+    for (int j = 0; j < A_CH; ++j) {
+      u32x4 hi, lo;
+      tgb_split8(R.a[2 * j], R.a[2 * j + 1], hi, lo);
+      *reinterpret_cast<u32x4*>(a_ + RS * j * TGB_ROWB) = hi;
+      *reinterpret_cast<u32x4*>(a_ + PLANE_A + RS * j * TGB_ROWB) = lo;
+    }
+  };
+  auto store_b = [&](const Regs& R, int buf) {
+    char* b_ = lds + buf * BUF + 2 * PLANE_A + r0 * TGB_ROWB + c8 * 2;
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) {
+      if (BSPLIT) {
+        *reinterpret_cast<float4*>(b_ + RS * j * TGB_ROWB) = R.b[2 * j];
+        *reinterpret_cast<float4*>(b_ + PLANE_B + RS * j * TGB_ROWB) = R.b[2 * j + 1];
+      } else {
+        u32x4 hi, lo;
+        tgb_split8(R.b[2 * j], R.b[2 * j + 1], hi, lo);
+        *reinterpret_cast<u32x4*>(b_ + RS * j * TGB_ROWB) = hi;
+        *reinterpret_cast<u32x4*>(b_ + PLANE_B + RS * j * TGB_ROWB) = lo;
+      }
+    }
+  };
+
+  // fragment addressing: lane -> (row lane & 31, k group lane >> 5); k16 step ks reads bytes [32 ks + 16 g, +16) of its row
+  const int arow = wm * (BM / WM) + (lane & 31);
+  const int brow = wn * (BN / WN) + (lane & 31);
+  const int kb = (lane >> 5) * 16;
+  const char* a_base = lds + arow * TGB_ROWB + kb;
+  const char* b_base = lds + 2 * PLANE_A + brow * TGB_ROWB + kb;
+  struct Frag {
+    bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+  };
+  auto frag_load = [&](Frag& f, int buf, int ks) {
+    const char* a_s = a_base + buf * BUF + ks * 32;
+    const char* b_s = b_base + buf * BUF + ks * 32;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      f.ah[i] = *reinterpret_cast<const bf16x8*>(a_s + i * 32 * TGB_ROWB);
+      f.al[i] = *reinterpret_cast<const bf16x8*>(a_s + PLANE_A + i * 32 * TGB_ROWB);
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      f.bh[j] = *reinterpret_cast<const bf16x8*>(b_s + j * 32 * TGB_ROWB);
+      f.bl[j] = *reinterpret_cast<const bf16x8*>(b_s + PLANE_B + j * 32 * TGB_ROWB);
+    }
+  };
+  // small terms first; term outermost so that consecutive MFMAs hit different accumulators
+  auto frag_mfma = [&](const Frag& f) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+  };
+  constexpr int NMF = 3 * FM * FN;                              // MFMAs per k16 group
+  constexpr int NFR = 2 * (FM + FN);                            // fragment reads per k16 group
+  constexpr int VA = A_CH * 24, VB = BSPLIT ? 0 : B_CH * 24;    // split VALU per thread: 6 per pair, 4 pairs per 8 channels
+  constexpr int WA = 2 * A_CH, WBn = 2 * B_CH;                  // ds_write_b128 per thread
+
+  // one K-step: tile `cur` is computed, the tile in R (loaded two steps ago) goes to buffer cur ^ 1, R is refilled with the tile two
+  // steps ahead.
+  auto step = [&](Regs& R, int cur, bool live) {
+    if (SCHED == 0) {
+      store_a(R, cur ^ 1);
+      store_b(R, cur ^ 1);
+      load_into(R, live);
+      __builtin_amdgcn_sched_barrier(0);
+      Frag f;
+      frag_load(f, cur, 0);
+      frag_mfma(f);
+      frag_load(f, cur, 1);
+      frag_mfma(f);
+    } else {
+      Regs T = R;                     // the registers being stored (renamed by the compiler; the loads below overwrite R)
+      load_into(R, live);
+      __builtin_amdgcn_sched_barrier(0);
+      Frag f0, f1;
+      frag_load(f0, cur, 0);
+      frag_mfma(f0);
+      store_a(T, cur ^ 1);
+      frag_load(f1, cur, 1);
+      frag_mfma(f1);
+      store_b(T, cur ^ 1);
+      if (SCHED == 2) {
+        // pipeline: the k16-0 fragments, then per MFMA of group 0 a slice of the A split + its stores and the k16-1 fragment reads,
+        // then per MFMA of group 1 a slice of the B work
+        __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);                    // DS read: fragments of k16 group 0
+        constexpr int va = (VA + NMF - 1) / NMF, vb = (VB + NMF - 1) / NMF;
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, va, 0);                   // VALU: split of A
+          if (m % 3 == 2 && m / 3 < WA) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);          // DS write
+          if (m >= NMF - NFR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // DS read: k16 group 1
+        }
+        if (WA > NMF / 3) __builtin_amdgcn_sched_group_barrier(0x200, WA - NMF / 3, 0);
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (vb) __builtin_amdgcn_sched_group_barrier(0x002, vb, 0);
+          if (m % 3 == 2 && m / 3 < WBn) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      }
+    }
+    __syncthreads();
+  };
+
+  Regs q, r;
+  int issued = 0;
+  {
+    Regs t0;
+    load_into(t0, true); ++issued;
+    load_into(q, issued < nks); ++issued;
+    store_a(t0, 0);
+    store_b(t0, 0);
+    load_into(r, issued < nks); ++issued;
+  }
+  __syncthreads();
+  // invariant at the top of step s: tile s is in LDS buffer s & 1; tile s+1 sits in q (s even) or r (s odd), tile s+2 in the other
+  int s = 0;
+  for (; s + 2 < nks; s += 2) {
+    step(q, 0, issued < nks); ++issued;
+    step(r, 1, issued < nks); ++issued;
+  }
+  if (s + 1 < nks) {                  // two tiles left: s in buffer 0, s+1 in q
+    step(q, 0, false);
+    ++s;
+    Frag f;
+    frag_load(f, 1, 0); frag_mfma(f);
+    frag_load(f, 1, 1); frag_mfma(f);
+  } else {                            // one tile left, in buffer 0
+    Frag f;
+    frag_load(f, 0, 0); frag_mfma(f);
+    frag_load(f, 0, 1); frag_mfma(f);
+  }
+
+  if (it.slab >= 0) {   // split-K: row-major slab tile, a tapgemm_reduce launch follows (the fused combines are fp32-kernel only)
+    float* sl = p.slab + (size_t)it.slab * (BM * BN);
+    const int col_l = lane & 31;
+    const int rhalf = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r2 = 0; r2 < 16; ++r2) {
+          const int row = wm * (BM / WM) + i * 32 + (r2 & 3) + 8 * (r2 >> 2) + rhalf;
+          const int col = wn * (BN / WN) + j * 32 + col_l;
+          sl[row * BN + col] = acc[i][j][r2];
+        }
+    return;
+  }
+  tg_store<BM, BN, WM, WN>(p, it, cl, acc, wm, wn, lane);
+}
+
+// weights fp32 -> (hi plane | lo plane) bf16, element for element (TgParams::wsplit); once per layer
+__global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, long long n) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= n) return;
+  const float x0 = w[i], x1 = (i + 1 < n) ? w[i + 1] : 0.f;
+  unsigned hi, lo;
+  tgb_split2(x0, x1, hi, lo);
+  out[i] = (unsigned short)(hi & 0xFFFFu);
+  out[n + i] = (unsigned short)(lo & 0xFFFFu);
+  if (i + 1 < n) {
+    out[i + 1] = (unsigned short)(hi >> 16);
+    out[n + i + 1] = (unsigned short)(lo >> 16);
+  }
+}
+hipError_t launch_wsplit(const float* w, unsigned short* out, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(wsplit_kernel, dim3((unsigned)((n / 2 + 256) / 256)), dim3(256), 0, s, w, out, n);
+  return hipGetLastError();
+}
+
+template <int BM, int BN, int WM, int WN, bool BSPLIT, int SCHED>
+static hipError_t launch_bf16x3_v(const TgParams& p, int nitems, hipStream_t s) {
+  static bool attr_set = false;
+  const size_t lds = (size_t)2 * 2 * (BM + BN) * TGB_ROWB;
+  auto k = tapgemm_bf16x3_kernel<BM, BN, WM, WN, BSPLIT, SCHED>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, dim3(nitems), dim3(64 * WM * WN), lds, s, p);
+  return hipGetLastError();
+}
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_bf16x3(const TgParams& p, int nitems, hipStream_t s) {
+  if (p.wsplit) {
+    switch (p.bf_sched) {
+      case 0: return launch_bf16x3_v<BM, BN, WM, WN, true, 0>(p, nitems, s);
+      case 1: return launch_bf16x3_v<BM, BN, WM, WN, true, 1>(p, nitems, s);
+      case 2: return launch_bf16x3_v<BM, BN, WM, WN, true, 2>(p, nitems, s);
+    }
+  } else {
+    switch (p.bf_sched) {
+      case 0: return launch_bf16x3_v<BM, BN, WM, WN, false, 0>(p, nitems, s);
+      case 1: return launch_bf16x3_v<BM, BN, WM, WN, false, 1>(p, nitems, s);
+      case 2: return launch_bf16x3_v<BM, BN, WM, WN, false, 2>(p, nitems, s);
+    }
+  }
+  return hipErrorInvalidValue;
+}
+
 // split-K second pass: y = epilogue(sum of slabs).  Block = (tile, group of rows); float4 along channels; KP lanes share
 // one output element's slabs (contiguous chunks of the split index, combined in lane order through LDS): at batch 1 a
 // tile has tens of slabs and few tiles exist, so the pass is a latency chain unless the slab loads run in parallel.
@@ -833,6 +1197,9 @@ static hipError_t launch_cfg(const TgParams& p, int nitems, hipStream_t s) {
     return hipErrorInvalidValue;
   }
   switch (p.variant) {
+    case TG_VARIANT_BF16X3:   // opt-in: split-bf16 operands, 3 MFMAs per product; tiles whose rows fill whole staging passes only
+      if constexpr (BM % (16 * WM * WN) == 0 && BN % (16 * WM * WN) == 0 && BM * BN <= 128 * 128) return launch_bf16x3<BM, BN, WM, WN>(p, nitems, s);   // == tg_bf16x3_supported(cfg)
+      else return hipErrorInvalidValue;
     // the three production schedules (autotune candidates): 1 and 2 register-staged, 4 = three K-steps of loads in flight
     case 1: return launch_var<BM, BN, WM, WN, 1>(p, nitems, s);
     case 2: return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);

@@ -130,8 +130,8 @@ class IanError(RuntimeError):
     pass
 
 
-def box_probe(iters=1600, launches=250, stream=None):
-    """ian_box_probe: sustained fp32-MFMA rate of this box (register-only loop, launches of ~200 us at iters = 1600).
+def box_probe(iters=900, launches=250, stream=None):
+    """ian_box_probe: sustained fp32-MFMA rate of this box (register-only loop, launches of ~200 us at iters = 900).
     -> {"tflops": ..., "us_per_launch": ...}"""
     lib = load_library()
     tf, us = C.c_double(), C.c_double()

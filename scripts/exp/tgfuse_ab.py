@@ -108,7 +108,7 @@ def main():
     out["verdict"] = "epilogue costs %.2f %% at batch 64, %.2f %% on the batch-1 reconstruction, %.2f %% on the brush event (positive = HEAD slower than the no-fuse build)" % tuple(
         100.0 * (1.0 / out["B_over_A"][w] - 1.0) for w in ("step64_ms", "b1_recon_ms", "brush_p50_ms"))
     try:
-        out["box"] = L.box_probe(1600, 250, stream=st)
+        out["box"] = L.box_probe(900, 250, stream=st)
     except Exception as exc:  # noqa: BLE001
         out["box"] = {"error": str(exc)}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "ablation: negative-result variants of libian_ablation.so on a GPU box (run with -m ablation; not part of -m gpu)")
     # the CPU oracles (torch twins) run on the host cores: on a wide host (256 logical CPUs on the MI355X box) torch's
     # default of one thread per logical CPU is catastrophically oversubscribed for these 64x64 convolutions
     # (measured: batch-1 reconstruction 53 ms on 1 thread, 6 s on 256 threads) -- cap it

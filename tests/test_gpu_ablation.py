@@ -38,8 +38,11 @@ def test_ablation_library_builds_and_says_what_it_is():
     assert not L.is_ablation_build()                       # this process runs the product library
 
 
-@pytest.mark.gpu
+@pytest.mark.ablation      # NOT `gpu` (round-5 verdict item 7: the suite budget): run with `pytest -m ablation` on a GPU box; scripts/README.md
 def test_negative_result_variants_still_pass_their_parity_tests():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU in this environment")
     env = _ablation_env()
     sel = ("every_tile_config_and_split_policy or batch1_streaming_deconv_equals_the_tapgemm_form "
            "or eight_wave_tile_is_bitwise_the_four_wave_tile or gemm_epilogue_statistics_equal_colstats "

@@ -111,6 +111,52 @@ def test_brush_gradients_vs_reference_api(arch):
     _note("brush_grad_max_rel_err_" + arch, worst)
 
 
+@pytest.mark.parametrize("arch", ARCHS)
+def test_bf16x3_option_is_opt_in_and_inside_the_parity_bar(arch):
+    """ian_set_option("tg_bf16x3", 1): tap-GEMMs on the bf16 matrix cores with split operands (three MFMAs per product,
+    kernels_tapgemm.hip tapgemm_bf16x3_kernel) -- a labelled secondary of the bench line, never the default.  Held to the SAME
+    reference-executed fixture and the same 1e-4 bar as the exact-fp32 path (layers.py:476-481, IAN_simple.py:141-170 are what
+    these launches replace), with tg_bf16x3_min_m = 1 pushing every multi-image layer whose tile the kernel supports through it;
+    and at the benchmarked batch against the exact-fp32 HIP path on the same inputs.
+    The batch-1 chains stay exact fp32 under the option (tg_bf16x3_min_images = 2): the brush gradient API.py:59,64 is
+    DISCONTINUOUS in the forward activations (leaky-ReLU / ReLU kinks), and a 1e-5 forward error flips a unit under the patch --
+    measured 1.5e-3 / 3.0e-3 on patch 1 of this fixture with the batch-1 forward forced through the split-bf16 kernel
+    (scripts/exp/bf16x3_brush_debug.py), while split-bf16 BACKWARD-data alone is smooth: held to the bar here."""
+    from neural_photo_editor_amd import IAN
+    fx = np.load(os.path.join(GOLD, "ref_%s.npz" % arch))
+    m = IAN(os.path.join(CFG, arch + ".py"), True, params=S.make_params(arch, 1))
+    ref32 = model_for(arch)
+    try:
+        B = 64 if arch == "IAN_simple" else 16
+        xb = S.make_images(B, seed=100)
+        before = m.reconstruct(xb)
+        assert np.array_equal(before, ref32.reconstruct(xb))          # off by default: bitwise the fp32 path
+        m.handle.set_option("tg_bf16x3", 1)
+        m.handle.set_option("tg_bf16x3_min_m", 1)
+        x, zs = fx["x"], fx["z_sample"]
+        errs = {"z": rel(m.encode_images(x), fx["z"]), "xhat_of_z": rel(m.sample_at(fx["z"].astype(np.float32)), fx["xhat"]),
+                "x_sample": rel(m.sample_at(zs), fx["x_sample"]), "recon": rel(m.reconstruct(x), fx["xhat"])}
+        after = m.reconstruct(xb)
+        errs["recon_batch%d_vs_fp32_hip" % B] = rel(after, before)
+        assert not np.array_equal(after, before)                      # the option did switch kernels
+        z = zs[:1]
+        patches = fx["patches"].tolist()
+        for c1, r1, c2, r2 in patches:                                # batch 1: untouched by the option, bit for bit
+            assert np.array_equal(m.imgradRGB(c1, r1, c2, r2, red_rgb(), z), ref32.imgradRGB(c1, r1, c2, r2, red_rgb(), z))
+        m.handle.set_option("tg_bf16x3_min_images", 1)                # ... unless asked: backward-data launches only
+        m.handle.set_option("tg_bf16x3_fwd", 0)
+        g = 0.0
+        for k, (c1, r1, c2, r2) in enumerate(patches):
+            g = max(g, rel(m.imgradRGB(c1, r1, c2, r2, red_rgb(), z), fx["grad_rgb_%d" % k]),
+                    rel(m.imgrad(c1, r1, c2, r2, z), fx["grad_light_%d" % k]))
+        errs["brush_grad_split_bf16_backward_data_only"] = g
+        _note("bf16x3_max_rel_err_" + arch, errs)
+        for k, v in errs.items():
+            assert v < TOL, (k, v, errs)
+    finally:
+        m.close()
+
+
 def test_made_iaf_kernel_vs_reference_layers():
     """ian_k_made_iaf on the small-layer fixture: IAFLayer(z, MADE, MADE) as layers.py wires it."""
     import torch

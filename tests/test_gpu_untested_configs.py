@@ -185,8 +185,12 @@ def test_generator_update_at_the_benchmarked_batch():
     gen_loss = L["adv_gen"] + c["recon_weight"] * L["pixel_loss"] + c["feature_weight"] * L["feature_loss"] + L["l2_gen"]
     z_loss = c["feature_weight"] * L["feature_loss"] + c["recon_weight"] * L["pixel_loss"] + L["adv_gen"] + L["kl_div"] + L["l2_Z"]
     names = {"dec": list(tw.groups["dec"]), "Z": list(tw.groups["Z"])}
-    g_dec = torch.autograd.grad(gen_loss, [tw.P[n] for n in names["dec"]], retain_graph=True)
-    g_z = torch.autograd.grad(z_loss, [tw.P[n] for n in names["Z"]])
+    # ONE float64 backward instead of two (suite budget: this test was 213 of the suite's 817 s): the two losses differ only in terms the
+    # other group's parameters do not reach -- l2_gen is a function of decoder_params alone, kl_div and l2_Z of the encoder / Z_params
+    # alone -- so d(gen_loss)/d(dec) and d(z_loss)/d(Z) are both read off the gradient of gen_loss + kl_div + l2_Z
+    assert abs(float((gen_loss + L["kl_div"] + L["l2_Z"]) - (z_loss + L["l2_gen"]))) <= 1e-12 * abs(float(gen_loss))
+    g_all = torch.autograd.grad(gen_loss + L["kl_div"] + L["l2_Z"], [tw.P[n] for n in names["dec"] + names["Z"]])
+    g_dec, g_z = g_all[:len(names["dec"])], g_all[len(names["dec"]):]
     ref = {"dec": dict(zip(names["dec"], g_dec)), "Z": dict(zip(names["Z"], g_z))}
     xh, xg = [t.detach().numpy().astype(np.float32) for t in (tw.tensors["X_hat"], tw.tensors["X_gen"])]
     tr = Trainer(os.path.join(CFG, "IAN.py"), P, batch=NB)
