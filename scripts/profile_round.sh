@@ -7,7 +7,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 export IAN_TUNE_CACHE=$PWD/$OUT/tune.txt   # first (un-profiled) run tunes, profiled passes replay its choices
-BENCH="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-edit --no-train --no-full-ian $*"
+BENCH="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-edit --no-train --no-full-ian --no-bf16x3 $*"
 echo "$BENCH   (under rocprofv3 --kernel-trace --stats / --pmc <set>; scripts/profile_round.sh)" > $OUT/cmd.txt
 echo "== bench (full) ==" 
 if [ -z "${SKIP_FULL_BENCH:-}" ]; then timeout 600 python bench.py $* > $OUT/bench.json 2> $OUT/bench.err; tail -c 300 $OUT/bench.json; fi

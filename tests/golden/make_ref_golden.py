@@ -19,6 +19,8 @@ Fixtures:
                        MinibatchLayer, GaussianSampleLayer, IAFLayer, MADE)
   ref_IAN_simple.npz   API.IAN(IAN_simple.py): encode_images / sample_at / imgrad / imgradRGB, dnn=True and dnn=False
   ref_IAN.npz          API.IAN(IAN.py via a 3-line get_model(dnn=) shim) + sample_IAN.py's four functions
+  ref_session_IAN_simple.npz   one NPE.py editing session as the sequence of facade calls its callbacks make (infer, 6 brush events in photo
+                       mode with two colours / sizes, 3 scroll events, Reset), the numpy / scipy lines between them restated from NPE.py
   ref_train_IAN.npz    train_IAN.make_training_functions: update_gen / update_discrim metrics, every gradient
                        (recovered from the Adam first moments), parameter values after the two updates
 """
@@ -419,6 +421,98 @@ def gen_train(ref, out, tmp, B=4):
     print("  never trained:", [n for n in untouched if "bnorm" not in n and "_bn" not in n][:12])
 
 
+# ---- one editing session: the facade-call sequence of NPE.py's callbacks (no UI) ---------------------------------------------------
+# NPE.py itself cannot be imported (Python 2 print statements, Tkinter widgets built at import time: NPE.py:14-35, 60-130), so the few
+# numpy / scipy lines BETWEEN its model calls are restated here, dtype for dtype, each citing the line it follows; every model call is
+# the reference's own API.IAN method on the evaluating stand-in.  The stand-in computes in float64 where Theano (floatX=float32,
+# README.md:19-21) returns float32: results of model calls are cast to float32 before NPE's arithmetic touches them.
+SESSION_EVENTS = (
+    # (kind, payload): what the user does, in order.  Coordinates are canvas pixels (the output canvas is 4 x 64 wide, NPE.py:148)
+    ("infer", None),                         # NPE.py:239-279 on the synthetic stand-in for CelebAValid[val]
+    ("color", (230, 40, 30)),                # getColor NPE.py:353-359
+    ("size", 12),                            # d.get() NPE.py:100-101 -> brush_width 4
+    ("paint", (114, 113)), ("paint", (118, 114)), ("paint", (121, 118)), ("paint", (125, 121)),      # B1-Motion, NPE.py:192-235
+    ("color", (20, 60, 220)),
+    ("size", 28),                            # brush_width 8
+    ("paint", (40, 162)), ("paint", (47, 165)),
+    ("scroll", +1), ("scroll", +1), ("scroll", -1),     # NPE.py:305-316, at the rectangle the brush was left at
+    ("reset", None),                         # NPE.py:330-340
+)
+
+
+def brush_rect(ex, ey, dsize):
+    """move_mouse NPE.py:142-156 + the // 4 of NPE.py:202: (x1, y1, x2, y2) in 64-pixel space."""
+    x, y = ex // 4, ey // 4
+    bw = (dsize // 4) + 1
+    xmin = max(min(x - bw // 2, 64 - bw), 0)
+    ymin = max(min(y - bw // 2, 64 - bw), 0)
+    return xmin, ymin, xmin + bw, ymin + bw
+
+
+def gen_session(ref, arch, out, tmp):
+    """-> ref_session_<arch>.npz: inputs (GIM, the event list) and, after every event, the latent and what the canvas would show."""
+    import lasagne
+    import scipy.ndimage
+    to_tanh = lambda a: 2.0 * (a / 255.0) - 1.0           # NPE.py:37-38
+    from_tanh = lambda a: 255.0 * (a + 1) / 2.0           # NPE.py:40-41
+    f32 = lambda a: np.asarray(a).astype(np.float32)      # a Theano function's float32 return value
+    P = S.make_params(arch, 1)
+    if arch == "IAN":
+        P = S.make_train_params(P)
+    lasagne.random.set_rng(np.random.RandomState(6))
+    model = ref.API.IAN(workdir_for(arch, P, os.path.join(tmp, "session")), True)
+    GIM = np.uint8((S.make_images(1, seed=9)[0] + 1.0) * 127.5)         # stands in for np.load('CelebAValid.npz')['arr_0'][val]
+    fx = {"GIM": GIM}
+    Z = np.zeros((10, 10), np.float32)
+    myRGB = np.zeros((1, 3, 64, 64), dtype=np.float32)                   # NPE.py:87
+    dsize, rect = 12, (0, 0, 4, 4)
+    IM = RECON = ERROR = None
+    kinds, recs = [], []
+    for kind, arg in SESSION_EVENTS:
+        shown = None
+        if kind in ("infer", "reset"):                                    # NPE.py:257-279 / 330-340: the same five lines
+            IM = GIM
+            s_ = f32(model.encode_images(np.asarray([to_tanh(IM)], dtype=np.float32)))
+            Z = np.reshape(s_[0], np.shape(Z))
+            RECON = np.uint8(from_tanh(f32(model.sample_at(np.float32([Z.flatten()])))[0]))
+            ERROR = to_tanh(np.float32(IM)) - to_tanh(np.float32(RECON))
+            shown = IM
+            fx["%02d_RECON" % len(kinds)], fx["%02d_ERROR" % len(kinds)] = RECON, ERROR
+        elif kind == "color":
+            for i in range(3):
+                myRGB[0, i, :, :] = arg[i]                                # NPE.py:359
+        elif kind == "size":
+            dsize = arg
+        elif kind == "paint":                                             # NPE.py:199-231, photo mode (SAMPLE_FLAG = 0 after infer)
+            rect = brush_rect(arg[0], arg[1], dsize)
+            x1, y1, x2, y2 = rect
+            temp = np.asarray(f32(model.imgradRGB(x1, y1, x2, y2, np.float32(to_tanh(myRGB)), np.float32([Z.flatten()])))[0])
+            grad = temp.reshape((10, 10)) * (1 + (x2 - x1))
+            Z -= 0.05 * grad
+            DELTA = f32(model.sample_at(np.float32([Z.flatten()])))[0] - to_tanh(np.float32(RECON))
+            MASK = scipy.ndimage.gaussian_filter(np.min([np.mean(np.abs(DELTA), axis=0), np.ones((64, 64))], axis=0), 0.7)
+            D = MASK * DELTA + (1 - MASK) * ERROR
+            IM = np.uint8(from_tanh(to_tanh(RECON) + D))
+            shown = IM
+            fx["%02d_MASK" % len(kinds)] = MASK
+        elif kind == "scroll":                                            # NPE.py:310-316; event.delta = +-1
+            x1, y1, x2, y2 = rect
+            grad = np.reshape(f32(model.imgrad(x1, y1, x2, y2, np.float32([Z.flatten()])))[0], Z.shape) * (1 + (x2 - x1))
+            Z += np.sign(arg) * 0.1 * grad
+            shown = np.uint8(from_tanh(f32(model.sample_at(np.float32([Z.flatten()])))[0]))     # update_photo(None) NPE.py:110
+        assert Z.dtype == np.float32
+        k = len(kinds)
+        kinds.append(kind)
+        recs.append(list(rect) + [dsize] + [int(v) for v in myRGB[0, :, 0, 0]] + ([int(arg)] if kind == "scroll" else [0]))
+        fx["%02d_Z" % k] = Z.copy()
+        if shown is not None:
+            fx["%02d_shown" % k] = np.asarray(shown).copy()
+    fx["kinds"] = np.asarray(kinds)
+    fx["state"] = np.asarray(recs, np.int64)      # per event: x1, y1, x2, y2, brush size d, brush colour r g b, scroll delta
+    np.savez_compressed(out, **fx)
+    print("session %s: %d events, |Z| after infer %.3f, after the last scroll %.3f" % (arch, len(kinds), np.abs(fx["00_Z"]).max(), np.abs(fx["%02d_Z" % (len(kinds) - 2)]).max()))
+
+
 def main(which):
     logging.basicConfig(level=logging.ERROR)
     with reference_modules() as ref, tempfile.TemporaryDirectory() as tmp:
@@ -431,7 +525,9 @@ def main(which):
                 gen_inference(ref, arch, os.path.join(HERE, "ref_%s.npz" % arch), tmp)
         if "train" in which:
             gen_train(ref, os.path.join(HERE, "ref_train_IAN.npz"), tmp)
+        if "session" in which:
+            gen_session(ref, "IAN_simple", os.path.join(HERE, "ref_session_IAN_simple.npz"), tmp)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or ["masks", "layers", "IAN_simple", "IAN", "train"])
+    main(sys.argv[1:] or ["masks", "layers", "IAN_simple", "IAN", "train", "session"])

@@ -189,3 +189,25 @@ def test_paint_event_photo_mode(model):
     Zs, x = N.paint_event(model, Zg, (5, 5, 9, 9), rgb8)
     Zh = N.brush_step(model, Zh, (5, 5, 9, 9), rgb8)
     assert np.array_equal(Zs, Zh) and np.array_equal(x, model.sample_at(Zh.reshape(1, -1))[0])
+
+
+def test_npe_session_replay_vs_reference_executed_session(model):
+    """One whole NPE.py editing session -- infer, 6 brush events in photo mode (two colours, two brush sizes), 3 scroll events, Reset --
+    as the sequence of facade calls its callbacks make (NPE.py:192-235, 239-279, 305-316, 330-340), recorded by running the reference's
+    own API.IAN on the evaluating stand-in (tests/golden/ref_session_IAN_simple.npz <- make_ref_golden.py; the numpy / scipy lines between
+    the model calls restated from NPE.py).  Replayed through the INTEGRATION.md section 1 surface: encode_images, ian_decode_u8
+    (sample_at_uint8), ian_brush_step with the device photo blend (npe_ops.paint_event), ian_photo_blend, ian_brush_step in lighten
+    mode.  Bars: every latent and blend mask within 1e-4 (the north-star tolerance on float32 values); canvas bytes equal to the
+    reference's except where a float32 image value sits on a uint8 truncation boundary -- at most one level on at most 0.2 % of the
+    pixels of an image (measured and recorded in gpurun_out/diag/npe_session.json)."""
+    import json
+    from session_replay import replay, compare
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "ref_session_IAN_simple.npz"))
+    events = replay(model, fx)
+    worst = compare(events, fx, tol=1e-4, max_off_by_one_frac=2e-3)
+    assert [e["kind"] for e in events].count("paint") == 6 and [e["kind"] for e in events].count("scroll") == 3
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out", "diag"), exist_ok=True)
+        json.dump(worst, open(os.path.join(ROOT, "gpurun_out", "diag", "npe_session.json"), "w"), indent=1)
+    except OSError:
+        pass

@@ -216,6 +216,39 @@ def test_train_twin_vs_reference_training_functions():
             assert rel(v.ravel()[::stride], ref) < 2e-6, name
 
 
+# ---- one NPE.py editing session (facade-call sequence, no UI) -------------------------------------------------------------------
+class _TwinFacade:
+    """API.py's method names over the float64 torch twin of the oracle (a test double for tests/session_replay.py)."""
+
+    def __init__(self, tw):
+        self.tw = tw
+
+    def encode_images(self, x):
+        return self.tw.np_encode(np.asarray(x, np.float32)).astype(np.float32)
+
+    def sample_at(self, z):
+        return self.tw.np_decode(np.asarray(z, np.float32)).astype(np.float32)
+
+    def imgradRGB(self, c1, r1, c2, r2, rgb, z):
+        return np.asarray(self.tw.imgradRGB(c1, r1, c2, r2, np.asarray(rgb, np.float32), np.asarray(z, np.float32)), np.float64).astype(np.float32)
+
+    def imgrad(self, c1, r1, c2, r2, z):
+        return np.asarray(self.tw.imgrad(c1, r1, c2, r2, np.asarray(z, np.float32)), np.float64).astype(np.float32)
+
+
+def test_npe_session_replay_oracle_vs_reference_executed_session():
+    """tests/golden/ref_session_IAN_simple.npz: infer -> 6 brush events in photo mode (two colours, two brush sizes) -> 3 scroll events ->
+    Reset, as NPE.py's callbacks sequence the reference's own API.IAN (NPE.py:192-235, 239-279, 305-316, 330-340).  The oracle's float64
+    twin, wrapped in API.py's method names and driven through npe_ops' host composition, must land on the same latents, blend masks and
+    canvas bytes: this pins the oracle (and npe_ops' restatement of the lines between the model calls) to the executed reference."""
+    import torch
+    from session_replay import replay, compare
+    fx = load("ref_session_IAN_simple.npz")
+    tw = TorchTwin("IAN_simple", O.make_params("IAN_simple", 1), dtype=torch.float64)
+    worst = compare(replay(_TwinFacade(tw), fx), fx, tol=1e-6, max_off_by_one_frac=1e-3)
+    assert worst["Z"] < 1e-6
+
+
 # ---- the fixtures are what the reference produces today (build container only) -------------------------------
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference checkout only exists in the build container")
 def test_fixtures_regenerate_from_the_reference(tmp_path):
@@ -228,7 +261,8 @@ def test_fixtures_regenerate_from_the_reference(tmp_path):
         mk.gen_made_masks(ref, str(tmp_path / "m.npz"))
         mk.gen_layers(ref, str(tmp_path / "l.npz"))
         mk.gen_inference(ref, "IAN_simple", str(tmp_path / "s.npz"), str(tmp_path))
-    for new, old in (("m.npz", "ref_made_masks.npz"), ("l.npz", "ref_layers.npz"), ("s.npz", "ref_IAN_simple.npz")):
+        mk.gen_session(ref, "IAN_simple", str(tmp_path / "e.npz"), str(tmp_path))
+    for new, old in (("m.npz", "ref_made_masks.npz"), ("l.npz", "ref_layers.npz"), ("s.npz", "ref_IAN_simple.npz"), ("e.npz", "ref_session_IAN_simple.npz")):
         a, b = np.load(str(tmp_path / new)), load(old)
         assert sorted(a.files) == sorted(b.files)
         for k in a.files:   # float64 sums may be re-associated between runs (threaded torch-CPU convolutions)
