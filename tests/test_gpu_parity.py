@@ -260,6 +260,14 @@ def test_errors_surface_as_exceptions():
     # empty patch: mean over nothing; the reference would give NaN, we return a zero gradient without crashing
     g = m.imgrad(5, 5, 5, 5, np.zeros((1, 100), np.float32))
     assert np.all(g == 0)
+    # n > 1 latents: API.py:59,64 differentiate a loss on X_hat[0] with respect to the WHOLE Z -> Z's shape, rows 1.. exactly zero
+    # (INTEGRATION.md section 1 lists the three deviations above and this agreement)
+    z3 = O.make_latents(3, seed=4)
+    rgb = np.full((1, 3, 64, 64), -1.0, np.float32)
+    for g3, g1 in ((m.imgrad(10, 12, 20, 30, z3), m.imgrad(10, 12, 20, 30, z3[:1])),
+                   (m.imgradRGB(10, 12, 20, 30, rgb, z3), m.imgradRGB(10, 12, 20, 30, rgb, z3[:1]))):
+        assert g3.shape == (3, 100) and g1.shape == (1, 100)
+        assert np.array_equal(g3[:1], g1) and np.all(g3[1:] == 0)
 
 
 @pytest.mark.parametrize("arch", O.ARCHS)
