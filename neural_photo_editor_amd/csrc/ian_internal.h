@@ -356,10 +356,18 @@ struct WgParams {
   long long slab_total;
   unsigned x_bytes, dy_bytes;
 };
-enum WgConfig { WG_128x128 = 0, WG_32x128 = 1, WG_128x32 = 2, WG_128x128W8 = 3 /* 8 waves of 64x32 */ };
+enum WgConfig { WG_128x128 = 0, WG_32x128 = 1, WG_128x32 = 2, WG_128x128W8 = 3 /* 8 waves of 64x32 */, WG_128x128P = 4 /* the same tile, software-pipelined K loop */, WG_128x128P2 = 5 /* ... rotated, three fragment buffers */ };
 hipError_t launch_tapwgrad(int cfg, const WgParams& p, int nitems, hipStream_t s);
 hipError_t launch_wgrad_reduce(const float* partial, long long slab_total, int nsplit, const int* inv, float* out,
                                long long count, int accumulate, hipStream_t s);
+// the slab -> reference map of a layer when it is affine (kernels_wgrad.hip wgrad_reduce_tiled_kernel); valid == false keeps the gather
+struct WgReduceTiledDesc {
+  bool valid = false;
+  int ntaps = 0, CoutPad = 0, CinPad = 0, Cout = 0, Cin = 0, tco = 16, tci = 16, s_co = 0, s_ci = 0;
+  unsigned char tap_off[48] = {0}, tap_inv[48] = {0};
+};
+hipError_t launch_wgrad_reduce_tiled(const WgReduceTiledDesc& d, const float* partial, long long slab_total, int nsplit, float* out,
+                                     int accumulate, hipStream_t s);
 hipError_t launch_gather_pack(const float* src, const int* map, float* dst, long long count, hipStream_t s);
 
 constexpr int MDC_MAX_BRANCH = 5;  // base 3x3 + up to IAN_MAX_SCALES dilated branches

@@ -131,6 +131,8 @@ struct Options {
   int tg_bf16x3_fwd = 1, tg_bf16x3_bwd = 1;   // which epilogue modes (forward / backward-data launches) the option applies to
   int tg_reduce_kp = 4;              // split-K reduce: lanes sharing one output element's slabs when a tile has >= 8 slabs
   int wg_w8 = 1;                     // tapwgrad: 8-wave 128x128 workgroups (16 waves per CU instead of 8)
+  int wg_pipe = 1;                   // tapwgrad: the software-pipelined K loop of the 8-wave tile (tapwgrad_p_kernel; 0 = the compiler-scheduled loop, bitwise the same)
+  int wg_reduce_tiled = 1;           // tapwgrad's split reduce scatters to the reference layout through LDS (wgrad_reduce_tiled_kernel; 0 = the gather, bitwise the same)
   int wg_xcd_split = 1;              // tapwgrad: all items of one pixel range go to one XCD (its rows are fetched into that L2 once), split count a
                                      // multiple of 8 (round 5); 0 = round 4's (split, tap) order
   int wg_target_items = 1024;        // tapwgrad: split the pixel range until taps x channel tiles x splits reaches this many workgroups

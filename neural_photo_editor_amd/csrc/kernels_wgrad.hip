@@ -156,6 +156,207 @@ __global__ __launch_bounds__(64 * WM * WN) void tapwgrad_kernel(const WgParams p
     }
 }
 
+
+// ---- tapwgrad_p_kernel: the 8-wave 128x128 tile with a software-pipelined K loop (round 6) -----------------------------------
+// Same tile, same operands, same summation order per output element as tapwgrad_kernel<128,128,2,4> (bitwise the same partial
+// slabs); what changes is the schedule.  The compiler-scheduled loop above issues each LDS fragment read right before the two
+// MFMAs of the PREVIOUS k pair (128 cycles of cover for a 64-128+ cycle LDS round trip) and waits for the global loads of the next
+// tile at the bottom of the step: profiles/r06_wgrad.md shows 31 % of wave cycles parked (tapgemm's production schedule: 15 %) and
+// the matrix pipe 65-75 % busy.  Here, as in tapgemm's VAR 2:
+//   * fragments travel in GROUPS of four k pairs (8 MFMAs = 512 cycles per group), double-buffered in registers: the reads of
+//     group g+1 are in flight during the MFMAs of group g;
+//   * the A operand (64 output channels of the wave) is ONE ds_read_b64 per k pair: a lane takes channels 2l, 2l+1 of its k row,
+//     .x feeds the MFMA block of the EVEN channels, .y the block of the ODD ones (a permutation of which accumulator holds which
+//     row; 256 B per 32 lanes, conflict free) -- half the LDS instructions of two ds_read_b32;
+//   * the global loads of K-step s+1 are issued at the top of step s, their ds_write_b128 after the second group (>= 1000 cycles
+//     later), one barrier per step, and the last group of a step is computed AFTER the barrier, covering it and the first reads
+//     of the new buffer;
+//   * the bounds tests of the loads are branch-free (the short-circuit && of the old loop compiled to exec-mask branches).
+template <int SCHED>
+__global__ __launch_bounds__(512, 2) void tapwgrad_p_kernel(const WgParams p) {
+  constexpr int BM = 128, BN = 128, WN = 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                      // [2][32][BM]
+  float* Bs = smem + 2 * WG_BK * BM;     // [2][32][BN]
+
+  const WgItem it = p.items[blockIdx.x];
+  if (it.m0 >= it.m1) return;
+  const TgClass cl = p.classes[it.cls];
+  const TgTap tp = p.taps[it.tap];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+
+  // staging: thread -> (row s_r + 16 j of the 32-row K-step, 16-byte chunk s_c of the 128-channel row), the same for both operands
+  const int s_c = (tid & 31) * 4, s_r = tid >> 5;
+  const bool a_col_ok = (it.co0 + s_c) < p.dy_stride;  // channel-tile overhang reads as zero
+  const bool b_col_ok = (it.ci0 + s_c) < p.Cin;
+  const int qhw_mask = (1 << p.qhw_shift) - 1, qw_mask = (1 << p.qw_shift) - 1;
+  const int a_cbase = it.co0 + s_c, b_cbase = it.ci0 + s_c;
+  const int y0 = cl.py, x0 = cl.px, by = p.by + tp.dy, bx = p.bx + tp.dx;
+
+  float4 ra[2], rb[2];
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  int mbase = it.m0;
+#define WGP_LOAD()                                                                                              \
+  {                                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                             \
+      const int m = mbase + s_r + 16 * j;                                                                       \
+      const int n = m >> p.qhw_shift, rem = m & qhw_mask;                                                       \
+      const int qy = rem >> p.qw_shift, qx = rem & qw_mask;                                                     \
+      const bool in = m < it.m1;                                                                                \
+      const unsigned aoff = (unsigned)((((n * p.OH + qy * p.so + y0) * p.OW + qx * p.so + x0) * p.dy_stride + a_cbase) * 4); \
+      ra[j] = wg_load4(yrsrc, (a_col_ok & in) ? aoff : 0xFFFFFFF0u);                                            \
+      const int iy = qy * p.si + by, ix = qx * p.si + bx;                                                       \
+      const bool okb = b_col_ok & in & ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);       \
+      const unsigned boff = (unsigned)((((n * p.IH + iy) * p.IW + ix) * p.Cin + b_cbase) * 4);                  \
+      rb[j] = wg_load4(xrsrc, okb ? boff : 0xFFFFFFF0u);                                                        \
+    }                                                                                                           \
+    mbase += WG_BK;                                                                                             \
+  }
+#define WGP_STORE(buf)                                                                                          \
+  {                                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                             \
+      *reinterpret_cast<float4*>(As + ((buf) * WG_BK + s_r + 16 * j) * BM + s_c) = ra[j];                       \
+      *reinterpret_cast<float4*>(Bs + ((buf) * WG_BK + s_r + 16 * j) * BN + s_c) = rb[j];                       \
+    }                                                                                                           \
+  }
+
+  const int half = lane >> 5, l31 = lane & 31;
+  const float* a_base = As + half * BM + wm * 64 + 2 * l31;   // float2: channels 2 l31, 2 l31 + 1 of the wave's 64
+  const float* b_base = Bs + half * BN + wn * 32 + l31;
+  // group g of a K-step = k pairs 4g .. 4g+3 = LDS rows 8g + 2q + half
+  auto frag_load = [&](int buf, int g, float2 (&av)[4], float (&bv)[4]) {
+    const float* a_s = a_base + (buf * WG_BK + 8 * g) * BM;
+    const float* b_s = b_base + (buf * WG_BK + 8 * g) * BN;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      av[q] = *reinterpret_cast<const float2*>(a_s + 2 * q * BM);
+      bv[q] = b_s[2 * q * BN];
+    }
+  };
+  auto frag_mfma = [&](const float2 (&av)[4], const float (&bv)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bv[q], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, bv[q], acc[1], 0, 0, 0);
+    }
+  };
+
+  const int nks = (it.m1 - it.m0 + WG_BK - 1) / WG_BK;
+#define WGP_SB() __builtin_amdgcn_sched_barrier(0)
+  // Every fragment read is PINNED one whole group (8 MFMAs, 512 cycles) ahead of its use: left alone, hipcc sinks the reads next to
+  // their MFMAs (ds_read, s_waitcnt lgkmcnt(0), v_mfma) to shorten live ranges.
+  if constexpr (SCHED == 1) {
+    // two fragment buffers; the reads of the new buffer's group 0 cross the loop's back edge -- and hipcc's waitcnt pass then
+    // waits with lgkmcnt(0) at the top of the body, i.e. also for the group-1 reads issued just before (kept for the A/B)
+    float2 av[4], aw[4];
+    float bv[4], bw[4];
+    WGP_LOAD();
+    WGP_STORE(0);
+    __syncthreads();
+    int cur = 0;
+    frag_load(0, 0, av, bv);
+    for (int s = 0; s < nks - 1; ++s) {
+      WGP_LOAD();                                 // K-step s+1: in flight during the MFMAs below
+      WGP_SB();
+      frag_load(cur, 1, aw, bw);
+      WGP_SB();
+      frag_mfma(av, bv);                          // group 0
+      WGP_SB();
+      frag_load(cur, 2, av, bv);
+      WGP_SB();
+      frag_mfma(aw, bw);                          // group 1
+      WGP_SB();
+      WGP_STORE(cur ^ 1);                         // the other buffer: nobody reads it during this step
+      WGP_SB();
+      frag_load(cur, 3, aw, bw);
+      WGP_SB();
+      frag_mfma(av, bv);                          // group 2
+      WGP_SB();
+      __syncthreads();                            // all reads of `cur` issued and returned, all writes of cur ^ 1 done
+      cur ^= 1;
+      frag_load(cur, 0, av, bv);
+      WGP_SB();
+      frag_mfma(aw, bw);                          // group 3 of the previous buffer covers the new buffer's first reads
+      WGP_SB();
+    }
+    frag_load(cur, 1, aw, bw);
+    WGP_SB();
+    frag_mfma(av, bv);
+    WGP_SB();
+    frag_load(cur, 2, av, bv);
+    WGP_SB();
+    frag_mfma(aw, bw);
+    WGP_SB();
+    frag_load(cur, 3, aw, bw);
+    WGP_SB();
+    frag_mfma(av, bv);
+    frag_mfma(aw, bw);
+  } else {
+    // three fragment buffers, the loop rotated so that NO LDS read is pending at the back edge (the barrier's lgkmcnt(0) has
+    // drained them): a step opens with the reads of its groups 0 and 1, then issues the next tile's global loads and computes
+    // the PREVIOUS step's group 3 (held in its own buffer across the barrier) while they return -- the waits inside the body
+    // are then exact counts (lgkmcnt(4): group 0 landed, group 1 still in flight)
+    float2 f0a[4], f1a[4], f3a[4];
+    float f0b[4], f1b[4], f3b[4];
+    WGP_LOAD();
+    WGP_STORE(0);
+    __syncthreads();
+    int cur = 0;
+    for (int s = 0; s < nks; ++s) {
+      const bool more = s + 1 < nks;
+      frag_load(cur, 0, f0a, f0b);
+      frag_load(cur, 1, f1a, f1b);
+      WGP_SB();
+      if (more) WGP_LOAD();                       // K-step s+1: in flight during the MFMAs below
+      WGP_SB();
+      if (s > 0) frag_mfma(f3a, f3b);             // group 3 of step s-1: covers the reads above and the load issue
+      WGP_SB();
+      frag_mfma(f0a, f0b);                        // group 0
+      WGP_SB();
+      frag_load(cur, 2, f0a, f0b);
+      WGP_SB();
+      frag_mfma(f1a, f1b);                        // group 1
+      WGP_SB();
+      if (more) WGP_STORE(cur ^ 1);               // the other buffer: nobody reads it during this step
+      WGP_SB();
+      frag_load(cur, 3, f3a, f3b);
+      WGP_SB();
+      frag_mfma(f0a, f0b);                        // group 2
+      WGP_SB();
+      if (more) __syncthreads();                  // all reads of `cur` returned, all writes of cur ^ 1 done
+      cur ^= 1;
+    }
+    frag_mfma(f3a, f3b);
+  }
+#undef WGP_SB
+#undef WGP_LOAD
+#undef WGP_STORE
+
+  // partial[split][tap][co][ci]; MFMA C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); block e holds the wave's
+  // channels 2 row + e
+  float* out = p.partial + (size_t)it.split * p.slab_total + (size_t)it.tap * p.CoutPad * p.CinPad;
+  const int ci = it.ci0 + wn * 32 + l31;
+  if (ci < p.CinPad) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int co = it.co0 + wm * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * half) + e;
+        if (co < p.CoutPad) out[(size_t)co * p.CinPad + ci] = acc[e][r];
+      }
+  }
+}
+
 template <int BM, int BN, int WM, int WN>
 static hipError_t launch_wg(const WgParams& p, int nitems, hipStream_t s) {
   static bool attr_set = false;
@@ -179,6 +380,20 @@ hipError_t launch_tapwgrad(int cfg, const WgParams& p, int nitems, hipStream_t s
     case WG_32x128: return launch_wg<32, 128, 1, 4>(p, nitems, s);
     case WG_128x32: return launch_wg<128, 32, 4, 1>(p, nitems, s);
     case WG_128x128W8: return launch_wg<128, 128, 2, 4>(p, nitems, s);
+    case WG_128x128P:
+    case WG_128x128P2: {
+      static bool attr_set = false;
+      const size_t lds = (size_t)2 * WG_BK * (128 + 128) * sizeof(float);
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tapwgrad_p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(tapwgrad_p_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+      }
+      if (cfg == WG_128x128P) hipLaunchKernelGGL(tapwgrad_p_kernel<1>, dim3(nitems), dim3(512), lds, s, p);
+      else hipLaunchKernelGGL(tapwgrad_p_kernel<2>, dim3(nitems), dim3(512), lds, s, p);
+      return hipGetLastError();
+    }
   }
   return hipErrorInvalidValue;
 }
@@ -201,6 +416,81 @@ hipError_t launch_wgrad_reduce(const float* partial, long long slab_total, int n
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, slab_total, nsplit, inv, out, count,
                      accumulate);
+  return hipGetLastError();
+}
+
+// ---- wgrad_reduce_tiled_kernel (round 6): the same sums, the scatter to the reference layout through LDS --------------------------
+// wgrad_reduce_kernel walks the REFERENCE parameter in order and gathers from the slabs: consecutive reference elements are the
+// taps of one (filter, channel) pair, i.e. one tap plane (CoutPad x Cin x 4 bytes) apart in every partial slab, and for the
+// transposed conv's (Cin, Cout, 5, 5) parameter also the filters are a whole slab row apart -- every 4-byte read pulls its own
+// 64-byte line: profiles/r06_wgrad.md measured 1.4-1.7 GB fetched per call where the partial slabs hold 0.13 GB, 195-244 us per
+// call on three decoder layers (as long as half their GEMM).  Here one workgroup owns a TCO x TCI block of (filter, channel) pairs
+// for ALL taps: it reads the slabs as they lie (16 bytes per lane, runs of TCI channels), sums the splits in the same fixed order
+// (0 + p_0 + p_1 + ...: bitwise the old result), parks the block in LDS and writes it out in REFERENCE order -- runs of
+// TCI x ntaps (conv) or TCO x ntaps (transposed conv) consecutive floats.  The host proves the layer's slab -> reference map affine
+// (reference index = filter * s_co + channel * s_ci + tap_off[tap]) before choosing this kernel; anything else keeps the gather.
+struct WgReduceTiled {
+  const float* partial;
+  float* out;
+  long long slab_total;
+  int nsplit, ntaps, plane /* CoutPad * CinPad */, CinPad, Cout, Cin, tco, tci, s_co, s_ci, accumulate;
+  unsigned char tap_off[48];   // slab tap -> offset inside the reference's tap block
+  unsigned char tap_inv[48];   // reference tap offset -> slab tap
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_tiled_kernel(const WgReduceTiled a) {
+  extern __shared__ float red[];   // [ntaps][tco * (tci + 4) + 1]: an ODD plane stride -- the write-out walks the taps of one pair with consecutive
+                                   // lanes, and a plane stride of 320 floats put all 25 of them on one bank (SQ_LDS_BANK_CONFLICT 92 %)
+  const int tci_p = a.tci + 4, lplane = a.tco * tci_p + 1;
+  const int tiles_ci = (a.Cin + a.tci - 1) / a.tci;
+  const int co0 = (blockIdx.x / tiles_ci) * a.tco, ci0 = (blockIdx.x % tiles_ci) * a.tci;
+  const int c4n = a.tci >> 2;                       // float4 per tile row
+  const int per_tap = a.tco * c4n, total4 = a.ntaps * per_tap;
+  for (int e = threadIdx.x; e < total4; e += 256) {
+    const int t = e / per_tap, rem = e - t * per_tap;
+    const int r = rem / c4n, c = (rem - r * c4n) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (co0 + r < a.Cout && ci0 + c < a.CinPad) {   // CinPad is a multiple of 32 and tci of 4: a float4 never straddles the row end
+      const float* src = a.partial + (size_t)t * a.plane + (size_t)(co0 + r) * a.CinPad + ci0 + c;
+#pragma unroll 8
+      for (int k = 0; k < a.nsplit; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * a.slab_total);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    float* q = red + t * lplane + r * tci_p + c;
+    q[0] = s.x; q[1] = s.y; q[2] = s.z; q[3] = s.w;
+  }
+  __syncthreads();
+  const int total = a.ntaps * a.tco * a.tci;
+  const bool ci_inner = a.s_ci < a.s_co;            // conv: (Cout, Cin, taps); transposed conv / dense: (Cin, Cout, taps)
+  for (int e = threadIdx.x; e < total; e += 256) {
+    int r, c, tp;
+    if (ci_inner) {
+      r = e / (a.tci * a.ntaps);
+      const int rem = e - r * (a.tci * a.ntaps);
+      c = rem / a.ntaps; tp = rem - c * a.ntaps;
+    } else {
+      c = e / (a.tco * a.ntaps);
+      const int rem = e - c * (a.tco * a.ntaps);
+      r = rem / a.ntaps; tp = rem - r * a.ntaps;
+    }
+    if (co0 + r >= a.Cout || ci0 + c >= a.Cin) continue;
+    const int t = a.tap_inv[tp];
+    const float v = red[t * lplane + r * tci_p + c];
+    float* o = a.out + (size_t)(co0 + r) * a.s_co + (size_t)(ci0 + c) * a.s_ci + tp;
+    *o = a.accumulate ? *o + v : v;
+  }
+}
+hipError_t launch_wgrad_reduce_tiled(const WgReduceTiledDesc& d, const float* partial, long long slab_total, int nsplit, float* out,
+                                     int accumulate, hipStream_t s) {
+  WgReduceTiled a;
+  a.partial = partial; a.out = out; a.slab_total = slab_total; a.nsplit = nsplit; a.ntaps = d.ntaps; a.plane = d.CoutPad * d.CinPad;
+  a.CinPad = d.CinPad; a.Cout = d.Cout; a.Cin = d.Cin; a.tco = d.tco; a.tci = d.tci; a.s_co = d.s_co; a.s_ci = d.s_ci;
+  a.accumulate = accumulate;
+  for (int t = 0; t < 48; ++t) { a.tap_off[t] = d.tap_off[t]; a.tap_inv[t] = d.tap_inv[t]; }
+  const int tiles = ((d.Cout + d.tco - 1) / d.tco) * ((d.Cin + d.tci - 1) / d.tci);
+  const size_t lds = (size_t)d.ntaps * (d.tco * (d.tci + 4) + 1) * sizeof(float);
+  hipLaunchKernelGGL(wgrad_reduce_tiled_kernel, dim3(tiles), dim3(256), lds, s, a);
   return hipGetLastError();
 }
 
