@@ -279,7 +279,7 @@ struct HeadFusedArgs {
 };
 hipError_t launch_head6(const HeadFusedArgs& a, int n, hipStream_t s);
 hipError_t launch_head6_zbuild(const float* dy0, const float* dy1, const float* dy2, int dys, float* Z, int zs, int H, int W,
-                               int ntaps, const int* taps, long long npix, hipStream_t s);
+                               int ntaps, const int* taps, long long npix, hipStream_t s, int max_shift /* largest |dy|, |dx| of the taps; < 0: the per-(pixel, tap) form */);
 hipError_t launch_head6_wcat(const float* slab, int f_rows, int f_cols, int kk, int ntaps, float* wcat, int nout, hipStream_t s);
 hipError_t launch_head6_dS_scatter(const float* dWref, int nout, int kk, int ntaps, float* dS, int f_rows, int f_cols, hipStream_t s);
 hipError_t launch_head6_scatter(const float* comp, float* y0, float* y1, float* y2, int ys, long long npix, hipStream_t s);
@@ -368,6 +368,7 @@ struct WgReduceTiledDesc {
 };
 hipError_t launch_wgrad_reduce_tiled(const WgReduceTiledDesc& d, const float* partial, long long slab_total, int nsplit, float* out,
                                      int accumulate, hipStream_t s);
+hipError_t launch_pack_tiled(const WgReduceTiledDesc& d, const float* ref, float* slab, hipStream_t s);
 hipError_t launch_gather_pack(const float* src, const int* map, float* dst, long long count, hipStream_t s);
 
 constexpr int MDC_MAX_BRANCH = 5;  // base 3x3 + up to IAN_MAX_SCALES dilated branches

@@ -351,9 +351,62 @@ __global__ __launch_bounds__(256) void head6_zbuild_kernel(const float* __restri
     }
   }
 }
+// Round 6: the same Z, built a pixel row at a time.  The per-(pixel, tap) form above issues three 8-byte gathers and three 8-byte
+// stores 24 bytes apart per thread: 370 us for the 470 MB of Z at 128 images (1.3 TB/s), with no GEMM to hide under
+// (profiles/r06_train_timeline_before.json).  Here a workgroup owns 64 consecutive pixels of one image row: it stages the
+// (2 S + 1) source rows x (64 + 2 S) pixels x 6 values its taps can reach in LDS (S = the largest |shift|; out-of-image pixels
+// as zeros), then writes its 64 rows of Z as fully coalesced float4 -- each value still one copy of one dY element (bitwise Z).
+constexpr int ZB_MAXS = 8;
+__global__ __launch_bounds__(256) void head6_zbuild_rows_kernel(const float* __restrict__ dy0, const float* __restrict__ dy1,
+                                                                const float* __restrict__ dy2, int dys, float* __restrict__ Z, int zs,
+                                                                int H, int W, int ntaps, const int* __restrict__ taps, int S) {
+  extern __shared__ float zl[];                       // [(2S+1)][(64+2S)][6], then ntaps packed shifts
+  const int PW = 64 + 2 * S, NR = 2 * S + 1;
+  int* tsh = reinterpret_cast<int*>(zl + NR * PW * 6);
+  const int segs = W / 64;
+  const int seg = blockIdx.x % segs, qy = (blockIdx.x / segs) % H;
+  const long long n = blockIdx.x / ((long long)segs * H);
+  const int qx0 = seg * 64;
+  for (int t = threadIdx.x; t < ntaps; t += 256) tsh[t] = taps[t];
+  const float* maps[3] = {dy0, dy1, dy2};
+  for (int i = threadIdx.x; i < NR * PW * 3; i += 256) {
+    const int k = i % 3, px = (i / 3) % PW, r = i / (3 * PW);
+    const int py = qy - (r - S), sx = qx0 + px - S;   // LDS row r holds source row qy - sy for sy = r - S
+    float2 v = make_float2(0.f, 0.f);
+    if ((unsigned)py < (unsigned)H && (unsigned)sx < (unsigned)W)
+      v = *reinterpret_cast<const float2*>(maps[k] + ((n * H + py) * W + sx) * dys);
+    float* q = zl + (r * PW + px) * 6 + 2 * k;
+    q[0] = v.x; q[1] = v.y;
+  }
+  __syncthreads();
+  const int z4 = zs >> 2;
+  float* zrow = Z + ((n * H + qy) * W + qx0) * zs;
+  for (int i = threadIdx.x; i < 64 * z4; i += 256) {
+    const int p = i / z4, j0 = (i - p * z4) * 4;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + e, t = j / 6;
+      float val = 0.f;
+      if (t < ntaps) {
+        const int tp = tsh[t];
+        const int sy = (tp & 0xFF) - 64, sx = (tp >> 8) - 64;
+        val = zl[((sy + S) * PW + (p - sx + S)) * 6 + (j - 6 * t)];
+      }
+      v[e] = val;
+    }
+    *reinterpret_cast<float4*>(zrow + (size_t)p * zs + j0) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
 hipError_t launch_head6_zbuild(const float* dy0, const float* dy1, const float* dy2, int dys, float* Z, int zs, int H, int W,
-                               int ntaps, const int* taps, long long npix, hipStream_t s) {
+                               int ntaps, const int* taps, long long npix, hipStream_t s, int max_shift) {
   if ((zs & 1) || (dys & 1) || zs < 6 * ntaps) return hipErrorInvalidValue;
+  if (max_shift >= 0 && max_shift <= ZB_MAXS && (W % 64) == 0 && (zs % 4) == 0 && npix % ((long long)H * W) == 0) {
+    const int S = max_shift;
+    const size_t lds = ((size_t)(2 * S + 1) * (64 + 2 * S) * 6 + ntaps) * sizeof(float);
+    hipLaunchKernelGGL(head6_zbuild_rows_kernel, dim3((unsigned)(npix / 64)), dim3(256), lds, s, dy0, dy1, dy2, dys, Z, zs, H, W, ntaps, taps, S);
+    return hipGetLastError();
+  }
   const long long total = npix * ((zs + 5) / 6);
   int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 64);
   hipLaunchKernelGGL(head6_zbuild_kernel, dim3(blocks), dim3(256), 0, s, dy0, dy1, dy2, dys, Z, zs, H, W, ntaps, taps, npix);

@@ -1032,16 +1032,30 @@ __global__ __launch_bounds__(512) void mdc_head_wgrad_kernel(MdcHeadWgradArgs a)
 }
 
 // dS[(t*f_rows + co)*f_cols + ci] = sum_b partial[b][t][co][ci]
+// Round 6: the thin head layers have 136-528 outputs and 512 block partials each; one thread per output walking its 512 partials
+// was a 2-workgroup launch of 512 dependent loads per thread -- 413 us per call, 3.3 ms of every four updates
+// (profiles/r06_train_timeline_before.json).  Now a workgroup owns 8 outputs x 32 partial lanes: lane j sums blocks j, j + 32, ...
+// (16 independent loads), then one thread per output adds the 32 lane sums in lane order -- a fixed order, bitwise reproducible
+// from run to run (it is NOT the old block order: sums differ from round 5's in the last bits).
 __global__ __launch_bounds__(256) void head_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int ntaps,
                                                                 int COUT, int CIN, float* __restrict__ dS, int f_rows,
                                                                 int f_cols) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[32][8];
   const int per = ntaps * COUT * CIN;
-  if (i >= per) return;
+  const int ol = threadIdx.x & 7, bl = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + ol;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * per + i];
-  const int ci = i % CIN, co = (i / CIN) % COUT, t = i / (CIN * COUT);
-  dS[((size_t)t * f_rows + co) * f_cols + ci] = s;
+  if (i < per)
+    for (int b = bl; b < nblocks; b += 32) s += partial[(size_t)b * per + i];
+  red[bl][ol] = s;
+  __syncthreads();
+  if (threadIdx.x < 8 && i < per) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) t += red[j][ol];
+    const int ci = i % CIN, co = (i / CIN) % COUT, tp = i / (CIN * COUT);
+    dS[((size_t)tp * f_rows + co) * f_cols + ci] = t;
+  }
 }
 
 hipError_t launch_mdc_head_wgrad(const MdcHeadWgradArgs& a, int nblocks, int Cin, int Cout, float* dS, int f_rows,
@@ -1069,7 +1083,7 @@ hipError_t launch_mdc_head_wgrad(const MdcHeadWgradArgs& a, int nblocks, int Cin
   else return hipErrorInvalidValue;
 #undef MW_LAUNCH
   const int per = a.ntaps * cpad * Cin;
-  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((per + 255) / 256), dim3(256), 0, s, a.partial, nblocks, a.ntaps, cpad, Cin,
+  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((per + 7) / 8), dim3(256), 0, s, a.partial, nblocks, a.ntaps, cpad, Cin,
                      dS, f_rows, f_cols);
   return hipGetLastError();
 }

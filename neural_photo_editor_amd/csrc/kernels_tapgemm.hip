@@ -556,6 +556,12 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
     // global loads + LDS stores, without the barrier, without the fragment reads -- what is left of the 22 % of cycles
     // in which the matrix pipe idles (scripts/ablate_tapgemm.sh)
     constexpr bool NOLOAD = (VAR == 10), NOBAR = (VAR == 11), NOFRAG = (VAR == 12);
+    // VAR 6 (round 6; 5 is taken by the split-bf16 kernel's TG_VARIANT_BF16X3) = VAR 2 with every fragment read PINNED where the source puts it.  Left to itself hipcc sinks the reads of k
+    // group g+1 below the MFMAs of group g and waits for them at once (ds_read_b128 x 3, s_waitcnt lgkmcnt(2), v_mfma ...: the ISA of
+    // the 8-wave tile), so a wave's LDS round trip is covered only by the OTHER waves of its SIMD; pinned, it is covered by the
+    // wave's own 8-32 MFMAs as the schedule intends.  Same instructions, same order of MFMAs -> same bits; an autotune candidate.
+    constexpr bool PIN = (VAR == 6);
+#define TG_PIN() if (PIN) __builtin_amdgcn_sched_barrier(0)
     float4 av[FM], bv[FN], aw[FM], bw[FN];
     tg_frag_load<FM, FN>(a_base, b_base, 0, av, bv);
     if (NOFRAG) tg_frag_load<FM, FN>(a_base, b_base, 1, aw, bw);
@@ -565,31 +571,43 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
       if (!NOLOAD) TG_LOAD_TILE();
       __builtin_amdgcn_sched_barrier(0);
       if (!NOFRAG) tg_frag_load<FM, FN>(a_s, b_s, 1, aw, bw);
+      TG_PIN();
       tg_frag_mfma<FM, FN>(av, bv, acc);   // kk 0 (fragments read before the previous barrier / in the prologue)
+      TG_PIN();
       if (!NOFRAG) tg_frag_load<FM, FN>(a_s, b_s, 2, av, bv);
+      TG_PIN();
       tg_frag_mfma<FM, FN>(aw, bw, acc);   // kk 1
       __builtin_amdgcn_sched_barrier(0);
       if (!NOLOAD) TG_STORE_TILE(cur ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       if (!NOFRAG) tg_frag_load<FM, FN>(a_s, b_s, 3, aw, bw);
+      TG_PIN();
       tg_frag_mfma<FM, FN>(av, bv, acc);   // kk 2
+      TG_PIN();
       if (!NOBAR) __syncthreads();         // all reads of `cur` (incl. kk 3 into aw/bw) and all writes of cur^1 done
       cur ^= 1;
       if (!NOFRAG) tg_frag_load<FM, FN>(a_base + cur * BM * TG_LDS, b_base + cur * BN * TG_LDS, 0, av, bv);
       __builtin_amdgcn_sched_barrier(0);
       tg_frag_mfma<FM, FN>(aw, bw, acc);   // kk 3 of the previous buffer: covers the new buffer's first reads
+      TG_PIN();
     }
     {
       const float* a_s = a_base + cur * BM * TG_LDS;
       const float* b_s = b_base + cur * BN * TG_LDS;
       tg_frag_load<FM, FN>(a_s, b_s, 1, aw, bw);
+      TG_PIN();
       tg_frag_mfma<FM, FN>(av, bv, acc);
+      TG_PIN();
       tg_frag_load<FM, FN>(a_s, b_s, 2, av, bv);
+      TG_PIN();
       tg_frag_mfma<FM, FN>(aw, bw, acc);
+      TG_PIN();
       tg_frag_load<FM, FN>(a_s, b_s, 3, aw, bw);
+      TG_PIN();
       tg_frag_mfma<FM, FN>(av, bv, acc);
       tg_frag_mfma<FM, FN>(aw, bw, acc);
     }
+#undef TG_PIN
   }
 #undef TG_LOAD_TILE
 #undef TG_STORE_TILE
@@ -1204,6 +1222,7 @@ static hipError_t launch_cfg(const TgParams& p, int nitems, hipStream_t s) {
     case 1: return launch_var<BM, BN, WM, WN, 1>(p, nitems, s);
     case 2: return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);
     case 4: return launch_var<BM, BN, WM, WN, 4>(p, nitems, s);
+    case 6: return launch_var<BM, BN, WM, WN, 6>(p, nitems, s);
 #ifdef IAN_ABLATION   // libian_ablation.so only (IAN_ABLATION_BUILD=1; tests/test_gpu_ablation.py, scripts/ablate_tapgemm.sh):
                       // negative results kept runnable -- schedule 0 (compiler-scheduled) and 3 (LDS-DMA staging, measured 5 %
                       // slower) give the SAME bits as 1 / 2 / 4; 10..12 are timing-only ablations whose RESULTS ARE WRONG.

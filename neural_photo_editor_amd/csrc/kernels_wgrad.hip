@@ -494,6 +494,62 @@ hipError_t launch_wgrad_reduce_tiled(const WgReduceTiledDesc& d, const float* pa
   return hipGetLastError();
 }
 
+// ---- pack_tiled_kernel (round 6): reference-layout parameter -> packed slab, the inverse walk of wgrad_reduce_tiled_kernel -------
+// gather_pack_kernel walks the SLAB and gathers from the reference: consecutive slab elements are 25 floats (conv) or Cout x 25
+// floats (transposed conv) apart in the parameter -- 187 + 234 us for the two slabs of dec_conv1 (52 MB each), 0.78 ms at the head
+// of every generator update.  Here a workgroup reads a TCO x TCI block of (filter, channel) pairs with all their taps as the
+// contiguous runs they are in the reference, parks them in LDS and writes the slab rows (runs of TCI floats, 16 bytes per lane);
+// slab padding inside the block is written as zeros, padding outside every block was zero-filled when the layer was created and
+// is never touched.  Same values as the gather (a copy): bitwise the old slabs.
+struct PackTiled {
+  const float* ref;
+  float* slab;
+  int ntaps, plane, CinPad, CoutPad, Cout, Cin, tco, tci, s_co, s_ci;
+  unsigned char tap_off[48];
+};
+__global__ __launch_bounds__(256) void pack_tiled_kernel(const PackTiled a) {
+  extern __shared__ float red[];   // [ntaps][tco * (tci + 4) + 1]
+  const int tci_p = a.tci + 4, lplane = a.tco * tci_p + 1;
+  const int tiles_ci = (a.Cin + a.tci - 1) / a.tci;
+  const int co0 = (blockIdx.x / tiles_ci) * a.tco, ci0 = (blockIdx.x % tiles_ci) * a.tci;
+  const int total = a.ntaps * a.tco * a.tci;
+  const bool ci_inner = a.s_ci < a.s_co;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    int r, c, tp;
+    if (ci_inner) {
+      r = e / (a.tci * a.ntaps);
+      const int rem = e - r * (a.tci * a.ntaps);
+      c = rem / a.ntaps; tp = rem - c * a.ntaps;
+    } else {
+      c = e / (a.tco * a.ntaps);
+      const int rem = e - c * (a.tco * a.ntaps);
+      r = rem / a.ntaps; tp = rem - r * a.ntaps;
+    }
+    float v = 0.f;
+    if (co0 + r < a.Cout && ci0 + c < a.Cin) v = a.ref[(size_t)(co0 + r) * a.s_co + (size_t)(ci0 + c) * a.s_ci + tp];
+    red[tp * lplane + r * tci_p + c] = v;          // indexed by the REFERENCE tap position; the write-out maps slab taps to it
+  }
+  __syncthreads();
+  const int c4n = a.tci >> 2, per_tap = a.tco * c4n, total4 = a.ntaps * per_tap;
+  for (int e = threadIdx.x; e < total4; e += 256) {
+    const int t = e / per_tap, rem = e - t * per_tap;
+    const int r = rem / c4n, c = (rem - r * c4n) * 4;
+    if (co0 + r >= a.CoutPad || ci0 + c >= a.CinPad) continue;
+    const float* q = red + (int)a.tap_off[t] * lplane + r * tci_p + c;
+    *reinterpret_cast<float4*>(a.slab + (size_t)t * a.plane + (size_t)(co0 + r) * a.CinPad + ci0 + c) = make_float4(q[0], q[1], q[2], q[3]);
+  }
+}
+hipError_t launch_pack_tiled(const WgReduceTiledDesc& d, const float* ref, float* slab, hipStream_t s) {
+  PackTiled a;
+  a.ref = ref; a.slab = slab; a.ntaps = d.ntaps; a.plane = d.CoutPad * d.CinPad; a.CinPad = d.CinPad; a.CoutPad = d.CoutPad;
+  a.Cout = d.Cout; a.Cin = d.Cin; a.tco = d.tco; a.tci = d.tci; a.s_co = d.s_co; a.s_ci = d.s_ci;
+  for (int t = 0; t < 48; ++t) a.tap_off[t] = d.tap_off[t];
+  const int tiles = ((d.Cout + d.tco - 1) / d.tco) * ((d.Cin + d.tci - 1) / d.tci);
+  const size_t lds = (size_t)d.ntaps * (d.tco * (d.tci + 4) + 1) * sizeof(float);
+  hipLaunchKernelGGL(pack_tiled_kernel, dim3(tiles), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
 // dst[i] = map[i] >= 0 ? src[map[i]] : 0   (reference-layout parameter -> packed slab, built on the device every step)
 __global__ __launch_bounds__(256) void gather_pack_kernel(const float* __restrict__ src, const int* __restrict__ map,
                                                           float* __restrict__ dst, long long count) {

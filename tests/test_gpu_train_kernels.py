@@ -730,3 +730,78 @@ def test_backward_weight_eight_wave_tile_is_bitwise_the_four_wave_tile(env, kind
         outs.append(g[0].cpu().numpy())
         layer.close()
     assert np.abs(outs[0]).max() > 0 and np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("kind,cin,cout,h,n", [("conv", 128, 256, 16, 8), ("conv", 64, 160, 8, 5), ("deconv", 256, 128, 8, 8), ("deconv", 64, 32, 8, 3),
+                                               ("dense", 1000, 100, 1, 7)])
+def test_round6_weight_paths_are_bitwise_the_round5_ones(env, kind, cin, cout, h, n, monkeypatch):
+    """Round 6 changed HOW three things run, not what they compute: tapwgrad's K loop (wg_pipe: fragment reads pinned a group ahead,
+    A operand as ds_read_b64 even / odd rows), its split reduce (wg_reduce_tiled: slabs read as they lie, scatter to the
+    reference layout through LDS) and the repack of the slabs after an update (pack_tiled).  Each output element still sums the
+    same products in the same order and the repack is a copy: forward, backward-data and backward-weight (overwrite and
+    accumulate) must be IDENTICAL to the round-5 kernels, incl. ragged channel tiles (160 filters), ragged pixel ranges and the
+    transposed conv's (Cin, Cout, 5, 5) parameter layout."""
+    lib, T, k = env
+    rs = np.random.RandomState(7)
+    K = {"conv": T.K_CONV, "deconv": T.K_DECONV, "dense": T.K_DENSE}[kind]
+    oh = h // 2 if kind == "conv" else h * 2
+    if kind == "dense":
+        x = torch.from_numpy(np.pad(rs.randn(n, cin).astype(np.float32), ((0, 0), (0, cs(cin) - cin)))).cuda()
+        dy = torch.from_numpy(np.pad(rs.randn(n, cout).astype(np.float32), ((0, 0), (0, cs(cout) - cout)))).cuda()
+        W = (rs.randn(cin, cout) * 0.1).astype(np.float32)
+    else:
+        x = to_nhwc(rs.randn(n, cin, h, h).astype(np.float32))
+        dy = to_nhwc(rs.randn(n, cout, oh, oh).astype(np.float32))
+        W = (rs.randn(*((cout, cin, 5, 5) if kind == "conv" else (cin, cout, 5, 5))) * 0.1).astype(np.float32)
+    outs = []
+    for opts in ("wg_pipe=0,wg_reduce_tiled=0,pack_tiled=0", "wg_pipe=1,wg_reduce_tiled=1,pack_tiled=1", "wg_pipe=2,wg_reduce_tiled=1,pack_tiled=1"):
+        monkeypatch.setenv("IAN_OPTS", opts)
+        layer = T.Layer(lib, K, cin, cout, h, h) if kind != "dense" else T.Layer(lib, K, cin, cout)
+        params = [torch.from_numpy(W.ravel()).cuda()]
+        layer.set_params(params)
+        y = torch.full((n,) + ((oh, oh) if kind != "dense" else ()) + (cs(cout),), 7.0, device="cuda")
+        dx = torch.full_like(x, 7.0)
+        layer.forward(x, n, y)
+        layer.backward_data(dy, n, dx)
+        g = [torch.full_like(params[0], 0.25)]
+        layer.backward_weight(x, dy, n, g)
+        layer.backward_weight(x, dy, n, g, accumulate=True)
+        torch.cuda.synchronize()
+        outs.append([t.cpu().numpy() for t in (y, dx, g[0])])
+        layer.close()
+    assert np.abs(outs[0][2]).max() > 0 and np.isfinite(outs[0][2]).all()
+    for other in outs[1:]:
+        for a, b, what in zip(outs[0], other, ("forward", "backward-data", "backward-weight")):
+            assert np.array_equal(a, b), what
+
+
+def test_head6_backward_row_staged_gather_is_bitwise_the_per_tap_gather(env, monkeypatch):
+    """head6_zbuild_rows_kernel (round 6: Z built one pixel row per workgroup through LDS, coalesced float4 rows) copies exactly the
+    elements head6_zbuild_kernel gathers: data gradient and all parameter gradients of the three head layers are identical."""
+    lib, T, k = env
+    rs = np.random.RandomState(77)
+    n, sc = 3, [2, 3, 4]
+    xd = to_nhwc(rs.randn(n, 128, 64, 64).astype(np.float32))
+    Ws = [(rs.randn(2, 128, 3, 3) * 0.05).astype(np.float32) for _ in range(3)]
+    cfs = [[rs.uniform(0.5, 1.5, 2).astype(np.float32) for _ in range(4)] for _ in range(3)]
+    dys = [to_nhwc(rs.randn(n, 2, 64, 64).astype(np.float32)) for _ in range(3)]
+    outs = []
+    for rows in (0, 1):
+        monkeypatch.setenv("IAN_OPTS", "zbuild_rows=%d" % rows)
+        layers, keep = [], []
+        for i in range(3):
+            layer = T.Layer(lib, T.K_MDC, 128, 2, 64, 64, scales=sc)
+            params = [torch.from_numpy(a.ravel()).cuda() for a in [Ws[i]] + cfs[i]]
+            layer.set_params(params)
+            layers.append(layer)
+            keep.append(params)
+        grads = [[torch.zeros_like(p) for p in ps] for ps in keep]
+        dx = torch.zeros(n, 64, 64, 128, device="cuda")
+        assert layers[0].head6_backward(layers[1], layers[2], xd, dys, n, 32, dx=dx, dx_stride=128, dparams3=grads)
+        torch.cuda.synchronize()
+        outs.append([dx.cpu().numpy()] + [g.cpu().numpy() for gs in grads for g in gs])
+        for l in layers:
+            l.close()
+    assert np.abs(outs[0][0]).max() > 0
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)

@@ -165,8 +165,11 @@ def test_batch_norm_at_the_benchmarked_batch(env, rows_per_image, C, act):
     assert e["fwd"] < 2e-5 and e["dbeta"] < 1e-4 and e["dgamma"] < 1e-4 and e["dy"] < 1e-4, e
 
 
-def test_generator_update_at_the_benchmarked_batch():
-    """update_gen's gradients (decoder_params, Z_params: train_IAN.py:256-273) on 128 images vs float64 autograd of the
+def test_generator_update_at_a_quarter_of_the_benchmarked_batch():
+    """update_gen's gradients (decoder_params, Z_params: train_IAN.py:256-273) on 32 images (round 6: 128 until then -- 148 s of the
+    suite's 734, almost all of it the twin's float64 backward on the host; the kernels AT 128 images are held by the per-layer
+    tests of this file, by the 8 x 16 sharded step that must equal the single-process 128-image step (tests/test_gpu_dp.py) and by
+    the committed 128-image decomposition record, profiles/r05_decomposition_b128_gen.json) vs float64 autograd of the
     twin; the encoder passes on X_hat / X_gen are fed the twin's images, as in test_gpu_train.test_gradients_match_autograd.
     Bars are multiples of what a float32 evaluation of the SAME restatement (torch-CPU twin, float32 vs float64, these
     inputs; 8 minutes of CPU, so measured once and recorded here) moves each group by -- round 3, with the reference's
@@ -177,8 +180,9 @@ def test_generator_update_at_the_benchmarked_batch():
     TWIN32 = {"dec": (1.74e-3, 5.5e-3), "Z": (1.4e-4, 3.2e-3)}
     from neural_photo_editor_amd.trainer import Trainer
     P = make_train_params(O.make_params("IAN", 1))
-    X, Z = O.make_images(NB, seed=31), O.make_latents(NB, seed=32)
-    eps = np.random.RandomState(33).randn(NB, 100).astype(np.float32)
+    NBH = NB // 4
+    X, Z = O.make_images(NBH, seed=31), O.make_latents(NBH, seed=32)
+    eps = np.random.RandomState(33).randn(NBH, 100).astype(np.float32)
     tw = TrainTwin(P, dtype=torch.float64)
     c = tw.cfg
     L = tw.losses(X, Z, eps)
@@ -193,7 +197,7 @@ def test_generator_update_at_the_benchmarked_batch():
     g_dec, g_z = g_all[:len(names["dec"])], g_all[len(names["dec"]):]
     ref = {"dec": dict(zip(names["dec"], g_dec)), "Z": dict(zip(names["Z"], g_z))}
     xh, xg = [t.detach().numpy().astype(np.float32) for t in (tw.tensors["X_hat"], tw.tensors["X_gen"])]
-    tr = Trainer(os.path.join(CFG, "IAN.py"), P, batch=NB)
+    tr = Trainer(os.path.join(CFG, "IAN.py"), P, batch=NBH)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     tr.forward(dev(X), dev(Z), dev(eps), xhat_override=dev(xh), xgen_override=dev(xg))
     m = tr.metrics()
@@ -206,7 +210,7 @@ def test_generator_update_at_the_benchmarked_batch():
         got = tr.grads_numpy(gname)
         errs = sorted(((rel(got[name], r.numpy()), name) for name, r in ref[gname].items()), reverse=True)
         out[gname] = {"median": float(np.median([e for e, _ in errs])), "worst": errs[:5]}
-    diag("composed128", out)
+    diag("composed32", out)
     # median: 2 x the float32 twin's (round-3 verdict).  Worst tensor: the maximum of ~150 heavy-tailed draws; 1-ulp perturbations of
     # the layer outputs move it by 7x from seed to seed (9e-3 .. 6.3e-2 at 16 images, profiles/r04_fp32_conditioning.json), so one
     # float32 draw bounds another only within that spread: 8 x.  The sharp per-tensor guard is tests/test_gpu_decomposition.py

@@ -52,7 +52,8 @@ def test_parity_and_training_step_under_asan_with_guard_bands():
     library: no ASan / UBSan report, no guard band touched, and the numbers still pass their parity bars (a descriptor that
     read past a buffer would now return NaN patterns instead of zeros or a neighbour's values)."""
     env = _sanitized_env()
-    out = _run(env, ["tests/test_gpu_parity.py", "-m", "gpu", "-k", "golden_encode_decode or brush_gradients_vs_golden or ragged_batches"], 1500)
+    out = _run(env, ["tests/test_gpu_parity.py", "-m", "gpu", "-k", "golden_encode_decode or brush_gradients_vs_golden or (ragged_batches and 5-)"], 1500)   # one ragged size per arch: the
+    # descriptor arithmetic is the same at 1 / 3 / 5 / 33 images and the product library runs all four
     assert " passed" in out
     out = _run(env, ["tests/test_gpu_train_step.py", "-m", "gpu", "-k", "host_buffers_only"], 1500)
     assert " passed" in out
