@@ -364,6 +364,9 @@ hipError_t launch_wgrad_reduce(const float* partial, long long slab_total, int n
 struct WgReduceTiledDesc {
   bool valid = false;
   int ntaps = 0, CoutPad = 0, CinPad = 0, Cout = 0, Cin = 0, tco = 16, tci = 16, s_co = 0, s_ci = 0;
+  bool ci_inner = true;                       // which axis walks the reference contiguously (stride = ntaps)
+  const int* co_off = nullptr;                // device tables replacing co * s_co / ci * s_ci where a permutation makes that axis non-linear
+  const int* ci_off = nullptr;
   unsigned char tap_off[48] = {0}, tap_inv[48] = {0};
 };
 hipError_t launch_wgrad_reduce_tiled(const WgReduceTiledDesc& d, const float* partial, long long slab_total, int nsplit, float* out,

@@ -433,7 +433,9 @@ struct WgReduceTiled {
   const float* partial;
   float* out;
   long long slab_total;
-  int nsplit, ntaps, plane /* CoutPad * CinPad */, CinPad, Cout, Cin, tco, tci, s_co, s_ci, accumulate;
+  int nsplit, ntaps, plane /* CoutPad * CinPad */, CinPad, Cout, Cin, tco, tci, s_co, s_ci, accumulate, ci_inner;
+  const int* co_off;           // or nullptr: co * s_co
+  const int* ci_off;           // or nullptr: ci * s_ci
   unsigned char tap_off[48];   // slab tap -> offset inside the reference's tap block
   unsigned char tap_inv[48];   // reference tap offset -> slab tap
 };
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tiled_kernel(const WgReduceT
   }
   __syncthreads();
   const int total = a.ntaps * a.tco * a.tci;
-  const bool ci_inner = a.s_ci < a.s_co;            // conv: (Cout, Cin, taps); transposed conv / dense: (Cin, Cout, taps)
+  const bool ci_inner = a.ci_inner != 0;            // conv: (Cout, Cin, taps); transposed conv / dense: (Cin, Cout, taps)
   for (int e = threadIdx.x; e < total; e += 256) {
     int r, c, tp;
     if (ci_inner) {
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tiled_kernel(const WgReduceT
     if (co0 + r >= a.Cout || ci0 + c >= a.Cin) continue;
     const int t = a.tap_inv[tp];
     const float v = red[t * lplane + r * tci_p + c];
-    float* o = a.out + (size_t)(co0 + r) * a.s_co + (size_t)(ci0 + c) * a.s_ci + tp;
+    float* o = a.out + (size_t)(a.co_off ? a.co_off[co0 + r] : (co0 + r) * a.s_co) + (size_t)(a.ci_off ? a.ci_off[ci0 + c] : (ci0 + c) * a.s_ci) + tp;
     *o = a.accumulate ? *o + v : v;
   }
 }
@@ -486,7 +488,7 @@ hipError_t launch_wgrad_reduce_tiled(const WgReduceTiledDesc& d, const float* pa
   WgReduceTiled a;
   a.partial = partial; a.out = out; a.slab_total = slab_total; a.nsplit = nsplit; a.ntaps = d.ntaps; a.plane = d.CoutPad * d.CinPad;
   a.CinPad = d.CinPad; a.Cout = d.Cout; a.Cin = d.Cin; a.tco = d.tco; a.tci = d.tci; a.s_co = d.s_co; a.s_ci = d.s_ci;
-  a.accumulate = accumulate;
+  a.accumulate = accumulate; a.ci_inner = d.ci_inner ? 1 : 0; a.co_off = d.co_off; a.ci_off = d.ci_off;
   for (int t = 0; t < 48; ++t) { a.tap_off[t] = d.tap_off[t]; a.tap_inv[t] = d.tap_inv[t]; }
   const int tiles = ((d.Cout + d.tco - 1) / d.tco) * ((d.Cin + d.tci - 1) / d.tci);
   const size_t lds = (size_t)d.ntaps * (d.tco * (d.tci + 4) + 1) * sizeof(float);
@@ -504,7 +506,9 @@ hipError_t launch_wgrad_reduce_tiled(const WgReduceTiledDesc& d, const float* pa
 struct PackTiled {
   const float* ref;
   float* slab;
-  int ntaps, plane, CinPad, CoutPad, Cout, Cin, tco, tci, s_co, s_ci;
+  int ntaps, plane, CinPad, CoutPad, Cout, Cin, tco, tci, s_co, s_ci, ci_inner;
+  const int* co_off;
+  const int* ci_off;
   unsigned char tap_off[48];
 };
 __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackTiled a) {
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackTiled a) {
   const int tiles_ci = (a.Cin + a.tci - 1) / a.tci;
   const int co0 = (blockIdx.x / tiles_ci) * a.tco, ci0 = (blockIdx.x % tiles_ci) * a.tci;
   const int total = a.ntaps * a.tco * a.tci;
-  const bool ci_inner = a.s_ci < a.s_co;
+  const bool ci_inner = a.ci_inner != 0;
   for (int e = threadIdx.x; e < total; e += 256) {
     int r, c, tp;
     if (ci_inner) {
@@ -526,7 +530,8 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackTiled a) {
       r = rem / a.ntaps; tp = rem - r * a.ntaps;
     }
     float v = 0.f;
-    if (co0 + r < a.Cout && ci0 + c < a.Cin) v = a.ref[(size_t)(co0 + r) * a.s_co + (size_t)(ci0 + c) * a.s_ci + tp];
+    if (co0 + r < a.Cout && ci0 + c < a.Cin)
+      v = a.ref[(size_t)(a.co_off ? a.co_off[co0 + r] : (co0 + r) * a.s_co) + (size_t)(a.ci_off ? a.ci_off[ci0 + c] : (ci0 + c) * a.s_ci) + tp];
     red[tp * lplane + r * tci_p + c] = v;          // indexed by the REFERENCE tap position; the write-out maps slab taps to it
   }
   __syncthreads();
@@ -543,6 +548,7 @@ hipError_t launch_pack_tiled(const WgReduceTiledDesc& d, const float* ref, float
   PackTiled a;
   a.ref = ref; a.slab = slab; a.ntaps = d.ntaps; a.plane = d.CoutPad * d.CinPad; a.CinPad = d.CinPad; a.CoutPad = d.CoutPad;
   a.Cout = d.Cout; a.Cin = d.Cin; a.tco = d.tco; a.tci = d.tci; a.s_co = d.s_co; a.s_ci = d.s_ci;
+  a.ci_inner = d.ci_inner ? 1 : 0; a.co_off = d.co_off; a.ci_off = d.ci_off;
   for (int t = 0; t < 48; ++t) a.tap_off[t] = d.tap_off[t];
   const int tiles = ((d.Cout + d.tco - 1) / d.tco) * ((d.Cin + d.tci - 1) / d.tci);
   const size_t lds = (size_t)d.ntaps * (d.tco * (d.tci + 4) + 1) * sizeof(float);

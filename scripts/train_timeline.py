@@ -17,7 +17,7 @@ rows = list(csv.DictReader(open(src)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 mark = max(i for i, r in enumerate(rows) if "arange" in r["Kernel_Name"].lower())
 rows = rows[mark + 1:]
-GEMM = ("tapgemm_kernel", "tapwgrad_kernel", "head6_kernel", "mdc_head_wgrad", "conv1_mfma", "mdc_thin_tile", "tapgemm_bf16x3")
+GEMM = ("tapgemm_kernel", "tapwgrad", "head6_kernel", "mdc_head_wgrad", "conv1_mfma", "mdc_thin_tile", "tapgemm_bf16x3")
 
 
 def name(r):

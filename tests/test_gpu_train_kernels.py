@@ -733,7 +733,7 @@ def test_backward_weight_eight_wave_tile_is_bitwise_the_four_wave_tile(env, kind
 
 
 @pytest.mark.parametrize("kind,cin,cout,h,n", [("conv", 128, 256, 16, 8), ("conv", 64, 160, 8, 5), ("deconv", 256, 128, 8, 8), ("deconv", 64, 32, 8, 3),
-                                               ("dense", 1000, 100, 1, 7)])
+                                               ("dense", 1000, 100, 1, 7), ("dense_flat", 256 * 16, 200, 1, 6), ("dense_unflat", 100, 64 * 16, 1, 6)])
 def test_round6_weight_paths_are_bitwise_the_round5_ones(env, kind, cin, cout, h, n, monkeypatch):
     """Round 6 changed HOW three things run, not what they compute: tapwgrad's K loop (wg_pipe: fragment reads pinned a group ahead,
     A operand as ds_read_b64 even / odd rows), its split reduce (wg_reduce_tiled: slabs read as they lie, scatter to the
@@ -743,9 +743,10 @@ def test_round6_weight_paths_are_bitwise_the_round5_ones(env, kind, cin, cout, h
     transposed conv's (Cin, Cout, 5, 5) parameter layout."""
     lib, T, k = env
     rs = np.random.RandomState(7)
-    K = {"conv": T.K_CONV, "deconv": T.K_DECONV, "dense": T.K_DENSE}[kind]
+    K = {"conv": T.K_CONV, "deconv": T.K_DECONV}.get(kind, T.K_DENSE)
     oh = h // 2 if kind == "conv" else h * 2
-    if kind == "dense":
+    dense_kw = {"dense_flat": dict(flat=(256, 4, 4)), "dense_unflat": dict(unflat=(64, 4, 4))}.get(kind, {})   # DenseLayer after / before (C,H,W)
+    if kind.startswith("dense"):
         x = torch.from_numpy(np.pad(rs.randn(n, cin).astype(np.float32), ((0, 0), (0, cs(cin) - cin)))).cuda()
         dy = torch.from_numpy(np.pad(rs.randn(n, cout).astype(np.float32), ((0, 0), (0, cs(cout) - cout)))).cuda()
         W = (rs.randn(cin, cout) * 0.1).astype(np.float32)
@@ -756,10 +757,10 @@ def test_round6_weight_paths_are_bitwise_the_round5_ones(env, kind, cin, cout, h
     outs = []
     for opts in ("wg_pipe=0,wg_reduce_tiled=0,pack_tiled=0", "wg_pipe=1,wg_reduce_tiled=1,pack_tiled=1", "wg_pipe=2,wg_reduce_tiled=1,pack_tiled=1"):
         monkeypatch.setenv("IAN_OPTS", opts)
-        layer = T.Layer(lib, K, cin, cout, h, h) if kind != "dense" else T.Layer(lib, K, cin, cout)
+        layer = T.Layer(lib, K, cin, cout, h, h) if not kind.startswith("dense") else T.Layer(lib, K, cin, cout, **dense_kw)
         params = [torch.from_numpy(W.ravel()).cuda()]
         layer.set_params(params)
-        y = torch.full((n,) + ((oh, oh) if kind != "dense" else ()) + (cs(cout),), 7.0, device="cuda")
+        y = torch.full((n,) + ((oh, oh) if not kind.startswith("dense") else ()) + (cs(cout),), 7.0, device="cuda")
         dx = torch.full_like(x, 7.0)
         layer.forward(x, n, y)
         layer.backward_data(dy, n, dx)
