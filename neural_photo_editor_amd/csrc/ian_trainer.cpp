@@ -150,6 +150,12 @@ struct ian_trainer {
   int overlap_wgrad = 1;
   int wgrad_priority = 0;                           // weight-gradient stream created with the lowest stream priority (make_wgrad_stream)
   hipStream_t st2 = nullptr;
+  // TIMING-ONLY experiment (IAN_DUAL_CHAIN_TIMING=1, libian_ablation.so only; RESULTS ARE WRONG): the (Z_rand -> decoder -> encoder) chain of
+  // forward and backward on its own stream next to the (X -> encoder -> decoder -> encoder) chain, ignoring that both chains use the SAME
+  // layer objects' split-K / statistics workspaces and accumulate into the same gradient buffers -- what a real two-chain step (per-chain
+  // layer clones, private gradient accumulators) could gain at most
+  int dual_timing = 0;
+  hipStream_t stB = nullptr;
   std::vector<hipEvent_t> events;
   size_t ev_used = 0;
   hipStream_t last_stream = nullptr;               // stream of the previous entry: a different one is synchronised first
@@ -1140,6 +1146,32 @@ int dec_backward(ian_trainer* t, Bufs& D, std::map<std::string, BN>& bn, const f
   return 0;
 }
 
+
+// ---- timing-only two-chain experiment (see ian_trainer::dual_timing) -------------------------------------------------------------
+int chain_fork(ian_trainer* t) {   // stream B starts behind everything issued to the compute stream so far
+  if (!t->stB) THIP(hipStreamCreateWithFlags(&t->stB, hipStreamNonBlocking));
+  hipEvent_t e;
+  THIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  THIP(hipEventRecord(e, t->st));
+  THIP(hipStreamWaitEvent(t->stB, e, 0));
+  THIP(hipEventDestroy(e));
+  return 0;
+}
+int chain_join(ian_trainer* t) {   // the compute stream waits for stream B
+  hipEvent_t e;
+  THIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  THIP(hipEventRecord(e, t->stB));
+  THIP(hipStreamWaitEvent(t->st, e, 0));
+  THIP(hipEventDestroy(e));
+  return 0;
+}
+struct OnStreamB {                 // everything issued while this object lives goes to stream B
+  ian_trainer* t;
+  hipStream_t keep;
+  explicit OnStreamB(ian_trainer* tt) : t(tt), keep(tt->st) { t->st = t->stB; }
+  ~OnStreamB() { t->st = keep; }
+};
+
 // ---- the step -----------------------------------------------------------------------------------------------------------
 int forward(ian_trainer* t, const float* X, const float* Zr, const float* eps) {  // the three passes of train_IAN.py:116-149
   const int n = t->n, Z = t->cfg.num_latents;
@@ -1151,6 +1183,21 @@ int forward(ian_trainer* t, const float* X, const float* Zr, const float* eps) {
   if ((rc = refresh_weights(t))) return rc;
   t->X = X;
   t->eps = eps;
+  if (t->dual_timing) {   // TIMING ONLY: chain B concurrently on its own stream, workspaces shared without protection
+    if ((rc = chain_fork(t))) return rc;
+    if ((rc = enc_forward(t, t->EX, t->bnEX, X, 0, -1, 0, true))) return rc;
+    if ((rc = z_forward(t, t->EX["a4"], eps))) return rc;
+    if ((rc = dec_forward(t, t->DZ, t->bnDZ, t->ZS["z"], true))) return rc;
+    if ((rc = enc_forward(t, t->EH, t->bnEH, t->DZ["xhat"], 0, 1, 1, false))) return rc;
+    {
+      OnStreamB b(t);
+      TK(ian_k_grad_pass(Zr, Z, 0, t->zgen0, nullptr, 128, n, Z, 0, 0, t->st));
+      TK(ian_k_made_iaf(t->zgen0, t->zgen, t->made_w, t->made_b, n, Z, 128, t->st));
+      if ((rc = dec_forward(t, t->DG, t->bnDG, t->zgen, false))) return rc;
+      if ((rc = enc_forward(t, t->EG, t->bnEG, t->DG["xhat"], 0, 2, 2, false))) return rc;
+    }
+    return chain_join(t);
+  }
   if ((rc = enc_forward(t, t->EX, t->bnEX, X, 0, -1, 0, true))) return rc;  // p_X vs p1
   if ((rc = z_forward(t, t->EX["a4"], eps))) return rc;
   if ((rc = dec_forward(t, t->DZ, t->bnDZ, t->ZS["z"], true))) return rc;   // X_hat
@@ -1224,6 +1271,23 @@ int backward(ian_trainer* t, bool gen) {  // gradients of the update rules of tr
                      t->scalars + 40, t->st));  // pixel_loss (:169)
   TK(ian_k_nhwc_to_nchw(t->EH["dx"], 32, t->DZ["tmp_img"], n, 4096, 3, t->st));
   TK(ian_k_axpy(1.f, t->DZ["tmp_img"], t->DZ["dxhat"], (int64_t)n * 3 * 4096, 1, t->st));
+  if (t->dual_timing) {   // TIMING ONLY (see forward)
+    if ((rc = chain_fork(t))) return rc;
+    if ((rc = dec_backward(t, t->DZ, t->bnDZ, t->ZS["z"], gen, true))) return rc;
+    if ((rc = z_backward(t, t->DZ["dz"], t->EX["a4"]))) return rc;
+    if (gen) {
+      OnStreamB b(t);
+      if ((rc = enc_backward(t, t->EG, t->bnEG, 0, c.ags_weight / N, -1, 0.f, false, false, true))) return rc;
+      TK(ian_k_nhwc_to_nchw(t->EG["dx"], 32, t->DG["dxhat"], n, 4096, 3, t->st));
+      if ((rc = dec_backward(t, t->DG, t->bnDG, t->zgen, true, false))) return rc;
+    } else {
+      if ((rc = enc_backward(t, t->EX, t->bnEX, 0, c.dd_weight / N, -1, 0.f, false, true, false))) return rc;
+      if ((rc = enc_backward(t, t->EH, t->bnEH, 1, c.dg_weight / N, -1, 0.f, false, true, false))) return rc;
+      OnStreamB b(t);
+      if ((rc = enc_backward(t, t->EG, t->bnEG, 2, c.dg_weight / N, -1, 0.f, false, true, false))) return rc;
+    }
+    return chain_join(t);
+  }
   if ((rc = dec_backward(t, t->DZ, t->bnDZ, t->ZS["z"], gen, true))) return rc;
   if ((rc = z_backward(t, t->DZ["dz"], t->EX["a4"]))) return rc;
   if (gen) {
@@ -1371,6 +1435,9 @@ int ian_trainer_finalize(ian_trainer* t) {
   t->xin = dalloc(t, (size_t)t->n * 3 * 4096); t->zin = dalloc(t, (size_t)t->n * 100); t->epsin = dalloc(t, (size_t)t->n * 100);
   if (t->oom) return tfail(t, -20, "out of device memory while allocating the training step's buffers (batch %d per GPU)", t->n);
   if (const char* e = getenv("IAN_WGRAD_PRIORITY")) t->wgrad_priority = atoi(e);
+#ifdef IAN_ABLATION
+  if (const char* e = getenv("IAN_DUAL_CHAIN_TIMING")) t->dual_timing = atoi(e);   // timing-only, results wrong: libian_ablation.so only
+#endif
   if (make_wgrad_stream(t) != 0) t->st2 = nullptr;   // no second stream: weight gradients stay on the compute stream
   if (t->world > 1) THIP(hipStreamCreateWithFlags(&t->st_comm, hipStreamNonBlocking));
   if (t->exact && ((t->n & (t->n - 1)) || (t->world & (t->world - 1))))
