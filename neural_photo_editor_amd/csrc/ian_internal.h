@@ -303,6 +303,7 @@ struct DeconvSmallArgs {
   const float* shift;
   float* y;
   int H, W, xs, bands, act;
+  int balanced;        // Cout = 3: the 16 x 16 MFMA tiling, five blocks per SIMD (kernels_head.hip; option dec_out_bal)
 };
 hipError_t launch_deconv_small(const DeconvSmallArgs& a, int n, int Cout, hipStream_t s);
 

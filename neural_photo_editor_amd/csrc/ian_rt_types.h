@@ -140,6 +140,7 @@ struct Options {
   int wg_xcd_split = 1;              // tapwgrad: all items of one pixel range go to one XCD (its rows are fetched into that L2 once), split count a
                                      // multiple of 8 (round 5); 0 = round 4's (split, tap) order
   int wg_target_items = 1024;        // tapwgrad: split the pixel range until taps x channel tiles x splits reaches this many workgroups
+  int dec_out_bal = 1;               // dec_out (Cout = 3) on 16 x 16 MFMA blocks, five per SIMD (deconv_small_kernel<3, true>); 0 = the 32 x 32 tiling (six of eight waves)
   int mdc_thin_tile = 1;             // thin MDCL (G_b / B_b and their backward-data) with the input rows staged through LDS
   int b1_conv = 0;                   // batch-1 transposed convs and their backward-data as whole-contraction streaming launches
                                      // (kernels_b1.hip).  OFF: measured slower than tapgemm + reduce (brush event 0.178 vs 0.160 ms):

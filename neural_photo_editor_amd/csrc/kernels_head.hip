@@ -466,7 +466,7 @@ hipError_t launch_head_tail(const HeadTailArgs& a, int n, hipStream_t s) {
 constexpr int DS_W = 32;            // input width; M per step = 2 rows x 32 pixels
 constexpr int DS_RING = 8;
 
-template <int COUT>
+template <int COUT, bool BAL = false>
 __global__ __launch_bounds__(512, 2) void deconv_small_kernel(DeconvSmallArgs a) {
   constexpr int N = 25 * COUT;
   constexpr int NTILES = (N + 31) / 32;          // 3 for Cout = 3, 4 for Cout = 4
@@ -493,7 +493,31 @@ __global__ __launch_bounds__(512, 2) void deconv_small_kernel(DeconvSmallArgs a)
     else ++r_end;                                                   // r_end <= a.H: a.H is even and r_begin == 0
   }
 
+  // BAL (round 6, COUT = 3): the same contraction as 16 x 16 blocks of v_mfma_f32_16x16x4_f32.  The 32 x 32 form has 2 x 3 = 6 blocks
+  // for 8 waves: six waves work, and since a workgroup's waves land on the SIMDs in the order 0, 2, 1, 3, 0, 2, 1, 3 two SIMDs carry
+  // two of them and two carry one -- the matrix phase of a row pair lasts 2 x 64 MFMAs (8192 cycles) where the work is 6144 per
+  // SIMD.  75 columns are five 16-wide blocks (the 32-wide tiling pads to 96), 64 pixels four: 20 blocks, three for each of waves
+  // 0-3 and two for each of waves 4-7 = five per SIMD, 5120 cycles.  Wave w < 4 owns column block w for pixel blocks 0-2; wave
+  // 4 + i owns (column block i, pixel block 3) and (column block 4, pixel block i).
   float wreg[64];
+  const int l16 = lane & 15, kg = lane >> 4;
+  if constexpr (BAL) {
+    static_assert(COUT == 3, "the balanced 16x16 tiling is laid out for 75 columns");
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const int cb = sidx == 0 ? (wave & 3) : 4;
+      const int j = cb * 16 + l16;
+      const bool ok = (j < N) && (sidx == 0 || wave >= 4);
+      const int k = ok ? j / COUT : 0, co = ok ? j % COUT : 0;
+      const float* wp = a.w + ((size_t)k * 4 + co) * HD_CIN + kg * 4;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float4*>(wp + kk * 16);
+        wreg[sidx * 32 + kk * 4 + 0] = v.x; wreg[sidx * 32 + kk * 4 + 1] = v.y; wreg[sidx * 32 + kk * 4 + 2] = v.z; wreg[sidx * 32 + kk * 4 + 3] = v.w;
+      }
+    }
+  } else
   {
     const int j = wg * 32 + (lane & 31);
     const bool ok = (wg < NTILES) && (j < N);
@@ -545,6 +569,56 @@ __global__ __launch_bounds__(512, 2) void deconv_small_kernel(DeconvSmallArgs a)
   for (int r = r_begin; r < r_end; r += 2) {
     if (r + 2 < r_end) DS_LOAD(r + 2);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (BAL) {
+      typedef float hd_f32x4 __attribute__((ext_vector_type(4)));
+      // C layout of the 16 x 16 MFMA: col = lane & 15, row = 4 (lane >> 4) + i
+      const int kq = kg * 4;
+#define DS_M16(acc, av, wbase, kk)                                                                        \
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wreg[(wbase) + (kk) * 4 + 0], acc, 0, 0, 0);         \
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wreg[(wbase) + (kk) * 4 + 1], acc, 0, 0, 0);         \
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wreg[(wbase) + (kk) * 4 + 2], acc, 0, 0, 0);         \
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wreg[(wbase) + (kk) * 4 + 3], acc, 0, 0, 0);
+      if (wave < 4) {                              // column block `wave`, pixel blocks 0, 1, 2 (weight set 0)
+        hd_f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
+        const float* xb = Xs + l16 * HD_XS + kq;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const float4 a0 = *reinterpret_cast<const float4*>(xb + kk * 16);
+          const float4 a1 = *reinterpret_cast<const float4*>(xb + 16 * HD_XS + kk * 16);
+          const float4 a2 = *reinterpret_cast<const float4*>(xb + 32 * HD_XS + kk * 16);
+          DS_M16(c0, a0, 0, kk)
+          DS_M16(c1, a1, 0, kk)
+          DS_M16(c2, a2, 0, kk)
+        }
+        float* yb = Ys + (kq) * YS + wave * 16 + l16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          yb[i * YS] = c0[i];
+          yb[(16 + i) * YS] = c1[i];
+          yb[(32 + i) * YS] = c2[i];
+        }
+      } else {                                     // (column block i, pixel block 3) with set 0, (column block 4, pixel block i) with set 1
+        const int i4 = wave & 3;
+        hd_f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+        const float* xa = Xs + (48 + l16) * HD_XS + kq;
+        const float* xb = Xs + (i4 * 16 + l16) * HD_XS + kq;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const float4 a0 = *reinterpret_cast<const float4*>(xa + kk * 16);
+          const float4 a1 = *reinterpret_cast<const float4*>(xb + kk * 16);
+          DS_M16(c0, a0, 0, kk)
+          DS_M16(c1, a1, 32, kk)
+        }
+        float* ya = Ys + (48 + kq) * YS + i4 * 16 + l16;
+        float* yb = Ys + (i4 * 16 + kq) * YS + 64 + l16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ya[i * YS] = c0[i];
+          yb[i * YS] = c1[i];
+        }
+      }
+#undef DS_M16
+    } else
     if (wg < NTILES) {
       hd_f32x16 acc;
 #pragma unroll
@@ -622,6 +696,17 @@ hipError_t launch_deconv_small(const DeconvSmallArgs& a, int n, int Cout, hipStr
     }                                                                                                             \
     hipLaunchKernelGGL(k, dim3(n * a.bands), dim3(512), lds, s, a);                                               \
     return hipGetLastError();                                                                                     \
+  }
+  if (Cout == 3 && a.balanced) {
+    static bool attr = false;
+    auto k = deconv_small_kernel<3, true>;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      attr = true;
+    }
+    hipLaunchKernelGGL(k, dim3(n * a.bands), dim3(512), lds, s, a);
+    return hipGetLastError();
   }
   if (Cout == 3) DS_LAUNCH(3)
   DS_LAUNCH(4)
