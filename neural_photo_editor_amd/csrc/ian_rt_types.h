@@ -129,6 +129,7 @@ struct Options {
   int tg_bf16x3_wsplit = 1;          // weights pre-split once per layer (0: split at staging like the activations)
   int tg_bf16x3_sched = 1;           // K-loop schedule of tapgemm_bf16x3_kernel (0..2, kernels_tapgemm.hip)
   int tg_bf16x3_fwd = 1, tg_bf16x3_bwd = 1;   // which epilogue modes (forward / backward-data launches) the option applies to
+  int tg_tune_deep = 1;              // 1: autotune also times K-loop schedule 7 (the rotated schedule with two K-steps of loads in flight)
   int tg_tune_pin = 0;               // 1: autotune also times K-loop schedule 6 (schedule 2 with its fragment reads pinned; kernels_tapgemm.hip).  OFF: measured,
                                      // 44.28 / 44.03 k reconstructions/s without vs 44.13 / 44.01 k with the candidate: no gain, 25 % more tuning time
   int tg_reduce_kp = 4;              // split-K reduce: lanes sharing one output element's slabs when a tile has >= 8 slabs

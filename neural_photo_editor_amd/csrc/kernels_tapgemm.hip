@@ -401,6 +401,25 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
     }                                                                                                    \
   }
 #define TG_LOAD_TILE() TG_LOAD_INTO(ra, rb)
+// the same loads, BRANCH-FREE past the end of the item: a K-step beyond its range (LIVE false, wave-uniform) addresses out of range and the
+// hardware returns zeros without touching memory, so that a run-ahead loop body stays one basic block (VAR 7)
+#define TG_LOAD_LIVE_INTO(RA, RB, LIVE)                                                                  \
+  {                                                                                                      \
+    const bool live_ = (LIVE);                                                                           \
+    const TgTap tp = p.taps[cl.tap0 + (live_ ? tap : 0)];                                                \
+    const unsigned doff = (unsigned)(((tp.dy * p.IW + tp.dx) * p.Cin + (cstep << 5)) * 4);               \
+    _Pragma("unroll") for (int j = 0; j < A_CH; ++j) {                                                   \
+      const int iy = a_iy0[j] + tp.dy, ix = a_ix0[j] + tp.dx;                                            \
+      const bool ok = live_ & ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);         \
+      RA[j] = buf_load4(xrsrc, ok ? a_off[j] + doff : 0xFFFFFFF0u, 0);                                   \
+    }                                                                                                    \
+    const unsigned wsoff = live_ ? w_cls + (unsigned)tap * slab_bytes + (unsigned)(cstep << 7) : 0u;     \
+    _Pragma("unroll") for (int j = 0; j < B_CH; ++j) RB[j] = buf_load4(wrsrc, live_ ? w_row + j * w_rstep : 0xFFFFFFF0u, wsoff); \
+    if (++cstep == kpt) {                                                                                \
+      cstep = 0;                                                                                         \
+      ++tap;                                                                                             \
+    }                                                                                                    \
+  }
 #define TG_STORE_FROM(RA, RB, buf)                                                                              \
   {                                                                                                      \
     float* a_ = As + (buf) * BM * TG_LDS + r0 * TG_LDS + c4;                                             \
@@ -480,12 +499,70 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
       tg_frag_mfma<FM, FN>(aw, bw, acc);
     }
 #undef TG_DMA_TILE
-  } else if (VAR != 4) {
+  } else if (VAR != 4 && VAR != 7) {
   TG_LOAD_TILE();
   TG_STORE_TILE(0);
   __syncthreads();
   }
   if (DMA) {
+  } else if (VAR == 7) {
+    // ---- VAR 7 (round 6): the rotated schedule of VAR 2 with the loads of TWO K-steps in flight.  In VAR 2 the tile of step s+1 is
+    // requested at the top of step s and written to LDS after the second k group: 16-32 of the wave's own MFMAs (1-2 thousand
+    // cycles of its own, 4-8 thousand with the SIMD's other waves) cover an L2 hit but not a miss to the Infinity Cache / HBM under
+    // load, and the barrier makes every wave of the workgroup wait for the slowest load.  Here the tile written in step s was
+    // requested in step s-1: a whole K-step more of cover, for A_CH + B_CH more staging registers (two sets, used alternately: the
+    // loop body is unrolled by two so that their names are static).  Branch-free past the item's end (TG_LOAD_LIVE_INTO).
+    // Same MFMA order -> same bits as 1 / 2 / 4 / 6.
+    float4 ra1[A_CH], rb1[B_CH];
+    float4 av[FM], bv[FN], aw[FM], bw[FN];
+    TG_LOAD_TILE();                                   // step 0
+    TG_LOAD_LIVE_INTO(ra1, rb1, nks > 1);             // step 1
+    TG_STORE_TILE(0);
+    __syncthreads();
+    tg_frag_load<FM, FN>(a_base, b_base, 0, av, bv);
+    // invariant at the top of the loop: tile s is in LDS buffer 0, tile s+1 in (ra1, rb1) -- requested, maybe still in flight --,
+    // (ra, rb) free.  Two steps per trip, so the LDS buffer index and the register set of each step are compile-time constants.
+#define TG_DSTEP(CUR, LOADS, SA, SB)                                                                               \
+    {                                                                                                              \
+      const float* a_s = a_base + (CUR) * BM * TG_LDS;                                                             \
+      const float* b_s = b_base + (CUR) * BN * TG_LDS;                                                             \
+      LOADS                                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      tg_frag_load<FM, FN>(a_s, b_s, 1, aw, bw);                                                                   \
+      tg_frag_mfma<FM, FN>(av, bv, acc);               /* kk 0 */                                                  \
+      tg_frag_load<FM, FN>(a_s, b_s, 2, av, bv);                                                                   \
+      tg_frag_mfma<FM, FN>(aw, bw, acc);               /* kk 1 */                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      TG_STORE_FROM(SA, SB, (CUR) ^ 1);                /* the next tile, requested a whole K-step ago */           \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      tg_frag_load<FM, FN>(a_s, b_s, 3, aw, bw);                                                                   \
+      tg_frag_mfma<FM, FN>(av, bv, acc);               /* kk 2 */                                                  \
+      __syncthreads();                                                                                             \
+      tg_frag_load<FM, FN>(a_base + ((CUR) ^ 1) * BM * TG_LDS, b_base + ((CUR) ^ 1) * BN * TG_LDS, 0, av, bv);     \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      tg_frag_mfma<FM, FN>(aw, bw, acc);               /* kk 3 of the previous buffer */                           \
+    }
+    int s = 0;
+    for (; s + 2 < nks; s += 2) {
+      TG_DSTEP(0, TG_LOAD_TILE();, ra1, rb1)                          // tile s+2 exists
+      TG_DSTEP(1, TG_LOAD_LIVE_INTO(ra1, rb1, s + 3 < nks);, ra, rb)
+    }
+    if (s + 1 < nks) {                                                // two tiles left: s in buffer 0, s+1 in (ra1, rb1)
+      TG_DSTEP(0, , ra1, rb1)
+      cur = 1;
+    }
+#undef TG_DSTEP
+    {
+      const float* a_s = a_base + cur * BM * TG_LDS;
+      const float* b_s = b_base + cur * BN * TG_LDS;
+      tg_frag_load<FM, FN>(a_s, b_s, 1, aw, bw);
+      tg_frag_mfma<FM, FN>(av, bv, acc);
+      tg_frag_load<FM, FN>(a_s, b_s, 2, av, bv);
+      tg_frag_mfma<FM, FN>(aw, bw, acc);
+      tg_frag_load<FM, FN>(a_s, b_s, 3, aw, bw);
+      tg_frag_mfma<FM, FN>(av, bv, acc);
+      tg_frag_mfma<FM, FN>(aw, bw, acc);
+    }
   } else if (VAR == 4) {
     // ---- VAR 4: register queue three tiles deep.  With few images an item is a handful of K-steps whose 16-64 MFMAs
     // (0.4-1.7 us) cannot cover a 1-2 us weight fetch from the Infinity Cache: the one-step prefetch of the other schedules
@@ -612,6 +689,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
 #undef TG_LOAD_TILE
 #undef TG_STORE_TILE
 #undef TG_LOAD_INTO
+#undef TG_LOAD_LIVE_INTO
 #undef TG_STORE_FROM
 
   // ---- epilogue. C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
@@ -1223,6 +1301,7 @@ static hipError_t launch_cfg(const TgParams& p, int nitems, hipStream_t s) {
     case 2: return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);
     case 4: return launch_var<BM, BN, WM, WN, 4>(p, nitems, s);
     case 6: return launch_var<BM, BN, WM, WN, 6>(p, nitems, s);
+    case 7: return launch_var<BM, BN, WM, WN, 7>(p, nitems, s);
 #ifdef IAN_ABLATION   // libian_ablation.so only (IAN_ABLATION_BUILD=1; tests/test_gpu_ablation.py, scripts/ablate_tapgemm.sh):
                       // negative results kept runnable -- schedule 0 (compiler-scheduled) and 3 (LDS-DMA staging, measured 5 %
                       // slower) give the SAME bits as 1 / 2 / 4; 10..12 are timing-only ablations whose RESULTS ARE WRONG.

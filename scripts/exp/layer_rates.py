@@ -2,7 +2,7 @@
 backward-weight of every tap-GEMM layer of IAN.py at the benchmarked per-GPU batch, after the layer autotune.  The training
 profile (profiles/r0N_train_ian_b128.md) shows the same kernels while the weight-gradient stream shares the chip with the data
 path; the difference is what the overlap costs each kernel.
-  python scripts/exp/layer_rates.py [batch=128]  ->  gpurun_out/r05_layer_rates.json"""
+  python scripts/exp/layer_rates.py [batch=128]  ->  gpurun_out/r06_layer_rates.json"""
 import json
 import os
 import sys
@@ -86,4 +86,4 @@ for name, kind, ci, co, hw, sc, macs in LAYERS:
 tot = {k: sum(r[k + "_us"] for r in out) for k in ("forward", "backward_data", "backward_weight")}
 print("sums (us):", tot)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump({"batch": n, "layers": out, "sum_us": tot, "peak_tflops": PEAK}, open(os.path.join(ROOT, "gpurun_out", "r05_layer_rates.json"), "w"), indent=1)
+json.dump({"batch": n, "layers": out, "sum_us": tot, "peak_tflops": PEAK}, open(os.path.join(ROOT, "gpurun_out", "r06_layer_rates.json"), "w"), indent=1)
