@@ -357,7 +357,8 @@ struct WgParams {
   long long slab_total;
   unsigned x_bytes, dy_bytes;
 };
-enum WgConfig { WG_128x128 = 0, WG_32x128 = 1, WG_128x32 = 2, WG_128x128W8 = 3 /* 8 waves of 64x32 */, WG_128x128P = 4 /* the same tile, software-pipelined K loop */, WG_128x128P2 = 5 /* ... rotated, three fragment buffers */ };
+enum WgConfig { WG_128x128 = 0, WG_32x128 = 1, WG_128x32 = 2, WG_128x128W8 = 3 /* 8 waves of 64x32 */, WG_128x128P = 4 /* the same tile, software-pipelined K loop */, WG_128x128P2 = 5 /* ... rotated, three fragment buffers */,
+                WG_128x128P3 = 6 /* ... P with the loads of two K-steps in flight */ };
 hipError_t launch_tapwgrad(int cfg, const WgParams& p, int nitems, hipStream_t s);
 hipError_t launch_wgrad_reduce(const float* partial, long long slab_total, int nsplit, const int* inv, float* out,
                                long long count, int accumulate, hipStream_t s);

@@ -130,11 +130,13 @@ struct Options {
   int tg_bf16x3_sched = 1;           // K-loop schedule of tapgemm_bf16x3_kernel (0..2, kernels_tapgemm.hip)
   int tg_bf16x3_fwd = 1, tg_bf16x3_bwd = 1;   // which epilogue modes (forward / backward-data launches) the option applies to
   int tg_tune_deep = 1;              // 1: autotune also times K-loop schedule 7 (the rotated schedule with two K-steps of loads in flight)
+  int tg_tune_model = 1;             // 1: autotune also times the split limits a longest-first model of the launch ranks best (ian_rt_autotune.inc)
+  int tg_tune_final = 4;             // autotune: the N fastest candidates of the first pass (5 launches each) are timed again over 24 launches; 0 = first pass decides
   int tg_tune_pin = 0;               // 1: autotune also times K-loop schedule 6 (schedule 2 with its fragment reads pinned; kernels_tapgemm.hip).  OFF: measured,
                                      // 44.28 / 44.03 k reconstructions/s without vs 44.13 / 44.01 k with the candidate: no gain, 25 % more tuning time
   int tg_reduce_kp = 4;              // split-K reduce: lanes sharing one output element's slabs when a tile has >= 8 slabs
   int wg_w8 = 1;                     // tapwgrad: 8-wave 128x128 workgroups (16 waves per CU instead of 8)
-  int wg_pipe = 1;                   // tapwgrad: the software-pipelined K loop of the 8-wave tile (tapwgrad_p_kernel; 0 = the compiler-scheduled loop, bitwise the same)
+  int wg_pipe = 3;                   // tapwgrad: the software-pipelined K loop of the 8-wave tile (tapwgrad_p_kernel; 0 = the compiler-scheduled loop, bitwise the same)
   int zbuild_rows = 1;               // head6 backward: Z built a pixel row at a time through LDS (head6_zbuild_rows_kernel; 0 = per (pixel, tap), same bytes)
   int pack_tiled = 1;                // training layers repack their slabs after an update through LDS tiles (pack_tiled_kernel; 0 = the gather, same bytes)
   int wg_reduce_tiled = 1;           // tapwgrad's split reduce scatters to the reference layout through LDS (wgrad_reduce_tiled_kernel; 0 = the gather, bitwise the same)

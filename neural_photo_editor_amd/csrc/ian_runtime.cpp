@@ -8,7 +8,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <functional>
 #include <memory>
+#include <queue>
 #include <string>
 #include <vector>
 

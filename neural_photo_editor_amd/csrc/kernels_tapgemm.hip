@@ -499,13 +499,15 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
       tg_frag_mfma<FM, FN>(aw, bw, acc);
     }
 #undef TG_DMA_TILE
-  } else if (VAR != 4 && VAR != 7) {
+  } else if (VAR != 4 && VAR != 7 && VAR != 8 && VAR != 9) {
   TG_LOAD_TILE();
   TG_STORE_TILE(0);
   __syncthreads();
   }
   if (DMA) {
-  } else if (VAR == 7) {
+  } else if (VAR == 7 || VAR == 9) {
+    // VAR 9 (experiment): VAR 7 with the wave's priority raised while it issues a group of MFMAs (s_setprio 2 / 0)
+#define TG_PRIO(x) if (VAR == 9) __builtin_amdgcn_s_setprio(x)
     // ---- VAR 7 (round 6): the rotated schedule of VAR 2 with the loads of TWO K-steps in flight.  In VAR 2 the tile of step s+1 is
     // requested at the top of step s and written to LDS after the second k group: 16-32 of the wave's own MFMAs (1-2 thousand
     // cycles of its own, 4-8 thousand with the SIMD's other waves) cover an L2 hit but not a miss to the Infinity Cache / HBM under
@@ -529,18 +531,24 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
       LOADS                                                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
       tg_frag_load<FM, FN>(a_s, b_s, 1, aw, bw);                                                                   \
+      TG_PRIO(2);                                                                                                  \
       tg_frag_mfma<FM, FN>(av, bv, acc);               /* kk 0 */                                                  \
       tg_frag_load<FM, FN>(a_s, b_s, 2, av, bv);                                                                   \
       tg_frag_mfma<FM, FN>(aw, bw, acc);               /* kk 1 */                                                  \
+      TG_PRIO(0);                                                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
       TG_STORE_FROM(SA, SB, (CUR) ^ 1);                /* the next tile, requested a whole K-step ago */           \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
       tg_frag_load<FM, FN>(a_s, b_s, 3, aw, bw);                                                                   \
+      TG_PRIO(2);                                                                                                  \
       tg_frag_mfma<FM, FN>(av, bv, acc);               /* kk 2 */                                                  \
+      TG_PRIO(0);                                                                                                  \
       __syncthreads();                                                                                             \
       tg_frag_load<FM, FN>(a_base + ((CUR) ^ 1) * BM * TG_LDS, b_base + ((CUR) ^ 1) * BN * TG_LDS, 0, av, bv);     \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
+      TG_PRIO(2);                                                                                                  \
       tg_frag_mfma<FM, FN>(aw, bw, acc);               /* kk 3 of the previous buffer */                           \
+      TG_PRIO(0);                                                                                                  \
     }
     int s = 0;
     for (; s + 2 < nks; s += 2) {
@@ -550,6 +558,81 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
     if (s + 1 < nks) {                                                // two tiles left: s in buffer 0, s+1 in (ra1, rb1)
       TG_DSTEP(0, , ra1, rb1)
       cur = 1;
+    }
+#undef TG_DSTEP
+#undef TG_PRIO
+    {
+      const float* a_s = a_base + cur * BM * TG_LDS;
+      const float* b_s = b_base + cur * BN * TG_LDS;
+      tg_frag_load<FM, FN>(a_s, b_s, 1, aw, bw);
+      tg_frag_mfma<FM, FN>(av, bv, acc);
+      tg_frag_load<FM, FN>(a_s, b_s, 2, av, bv);
+      tg_frag_mfma<FM, FN>(aw, bw, acc);
+      tg_frag_load<FM, FN>(a_s, b_s, 3, aw, bw);
+      tg_frag_mfma<FM, FN>(av, bv, acc);
+      tg_frag_mfma<FM, FN>(aw, bw, acc);
+    }
+  } else if (VAR == 8) {
+    // ---- VAR 8 (round 6): VAR 7 with the loads of THREE K-steps in flight (three staging sets; six steps per trip so that buffer
+    // index and register set stay compile-time constants).  For the tiles whose K-step is short against an L2 / Infinity Cache
+    // round trip under load (64x64: 16 MFMAs per wave and step, 16 B/clk/CU of operand traffic).  Same MFMA order -> same bits.
+    float4 ra1[A_CH], rb1[B_CH], ra2[A_CH], rb2[B_CH];
+    float4 av[FM], bv[FN], aw[FM], bw[FN];
+    TG_LOAD_TILE();                                   // step 0
+    TG_LOAD_LIVE_INTO(ra1, rb1, nks > 1);             // step 1
+    TG_LOAD_LIVE_INTO(ra2, rb2, nks > 2);             // step 2
+    TG_STORE_TILE(0);
+    __syncthreads();
+    tg_frag_load<FM, FN>(a_base, b_base, 0, av, bv);
+#define TG_DSTEP(CUR, LOADS, SA, SB)                                                                               \
+    {                                                                                                              \
+      const float* a_s = a_base + (CUR) * BM * TG_LDS;                                                             \
+      const float* b_s = b_base + (CUR) * BN * TG_LDS;                                                             \
+      LOADS                                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      tg_frag_load<FM, FN>(a_s, b_s, 1, aw, bw);                                                                   \
+      tg_frag_mfma<FM, FN>(av, bv, acc);                                                                           \
+      tg_frag_load<FM, FN>(a_s, b_s, 2, av, bv);                                                                   \
+      tg_frag_mfma<FM, FN>(aw, bw, acc);                                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      TG_STORE_FROM(SA, SB, (CUR) ^ 1);                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      tg_frag_load<FM, FN>(a_s, b_s, 3, aw, bw);                                                                   \
+      tg_frag_mfma<FM, FN>(av, bv, acc);                                                                           \
+      __syncthreads();                                                                                             \
+      tg_frag_load<FM, FN>(a_base + ((CUR) ^ 1) * BM * TG_LDS, b_base + ((CUR) ^ 1) * BN * TG_LDS, 0, av, bv);     \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      tg_frag_mfma<FM, FN>(aw, bw, acc);                                                                           \
+    }
+    // invariant at the top of step s: tile s in LDS buffer s & 1, tiles s+1, s+2 in sets (s+1) % 3, (s+2) % 3, set s % 3 free
+    int s = 0;
+    for (; s + 6 < nks; s += 6) {                      // six non-final steps; tile s+j+3 exists for j <= 2, maybe not beyond
+      TG_DSTEP(0, TG_LOAD_TILE();, ra1, rb1)
+      TG_DSTEP(1, TG_LOAD_INTO(ra1, rb1);, ra2, rb2)
+      TG_DSTEP(0, TG_LOAD_INTO(ra2, rb2);, ra, rb)
+      TG_DSTEP(1, TG_LOAD_LIVE_INTO(ra, rb, s + 6 < nks);, ra1, rb1)
+      TG_DSTEP(0, TG_LOAD_LIVE_INTO(ra1, rb1, s + 7 < nks);, ra2, rb2)
+      TG_DSTEP(1, TG_LOAD_LIVE_INTO(ra2, rb2, s + 8 < nks);, ra, rb)
+    }
+    if (s + 1 < nks) {                                 // up to five non-final steps left
+      TG_DSTEP(0, TG_LOAD_LIVE_INTO(ra, rb, s + 3 < nks);, ra1, rb1)
+      cur = 1;
+      if (s + 2 < nks) {
+        TG_DSTEP(1, TG_LOAD_LIVE_INTO(ra1, rb1, s + 4 < nks);, ra2, rb2)
+        cur = 0;
+        if (s + 3 < nks) {
+          TG_DSTEP(0, TG_LOAD_LIVE_INTO(ra2, rb2, s + 5 < nks);, ra, rb)
+          cur = 1;
+          if (s + 4 < nks) {
+            TG_DSTEP(1, , ra1, rb1)
+            cur = 0;
+            if (s + 5 < nks) {
+              TG_DSTEP(0, , ra2, rb2)
+              cur = 1;
+            }
+          }
+        }
+      }
     }
 #undef TG_DSTEP
     {
@@ -1307,6 +1390,8 @@ static hipError_t launch_cfg(const TgParams& p, int nitems, hipStream_t s) {
                       // slower) give the SAME bits as 1 / 2 / 4; 10..12 are timing-only ablations whose RESULTS ARE WRONG.
                       // The shipped library contains none of them and rejects the option values.
     case 0: return launch_var<BM, BN, WM, WN, 0>(p, nitems, s);
+    case 8: if constexpr (BM * BN <= 128 * 64) return launch_var<BM, BN, WM, WN, 8>(p, nitems, s); else return launch_var<BM, BN, WM, WN, 7>(p, nitems, s);   // three K-steps in flight (small tiles): measured no better than 7
+    case 9: return launch_var<BM, BN, WM, WN, 9>(p, nitems, s);   // 7 + s_setprio around the MFMA groups (experiment)
     case 3: return launch_var<BM, BN, WM, WN, 3>(p, nitems, s);
     case 10: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 10>(p, nitems, s); return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);
     case 11: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 11>(p, nitems, s); return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);

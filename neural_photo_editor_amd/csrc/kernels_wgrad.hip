@@ -206,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void tapwgrad_p_kernel(const WgParams p) {
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   int mbase = it.m0;
-#define WGP_LOAD()                                                                                              \
+#define WGP_LOAD_INTO(RA, RB)                                                                                   \
   {                                                                                                             \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                             \
       const int m = mbase + s_r + 16 * j;                                                                       \
@@ -214,21 +214,23 @@ __global__ __launch_bounds__(512, 2) void tapwgrad_p_kernel(const WgParams p) {
       const int qy = rem >> p.qw_shift, qx = rem & qw_mask;                                                     \
       const bool in = m < it.m1;                                                                                \
       const unsigned aoff = (unsigned)((((n * p.OH + qy * p.so + y0) * p.OW + qx * p.so + x0) * p.dy_stride + a_cbase) * 4); \
-      ra[j] = wg_load4(yrsrc, (a_col_ok & in) ? aoff : 0xFFFFFFF0u);                                            \
+      RA[j] = wg_load4(yrsrc, (a_col_ok & in) ? aoff : 0xFFFFFFF0u);                                            \
       const int iy = qy * p.si + by, ix = qx * p.si + bx;                                                       \
       const bool okb = b_col_ok & in & ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);       \
       const unsigned boff = (unsigned)((((n * p.IH + iy) * p.IW + ix) * p.Cin + b_cbase) * 4);                  \
-      rb[j] = wg_load4(xrsrc, okb ? boff : 0xFFFFFFF0u);                                                        \
+      RB[j] = wg_load4(xrsrc, okb ? boff : 0xFFFFFFF0u);                                                        \
     }                                                                                                           \
     mbase += WG_BK;                                                                                             \
   }
-#define WGP_STORE(buf)                                                                                          \
+#define WGP_LOAD() WGP_LOAD_INTO(ra, rb)
+#define WGP_STORE_FROM(RA, RB, buf)                                                                             \
   {                                                                                                             \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                             \
-      *reinterpret_cast<float4*>(As + ((buf) * WG_BK + s_r + 16 * j) * BM + s_c) = ra[j];                       \
-      *reinterpret_cast<float4*>(Bs + ((buf) * WG_BK + s_r + 16 * j) * BN + s_c) = rb[j];                       \
+      *reinterpret_cast<float4*>(As + ((buf) * WG_BK + s_r + 16 * j) * BM + s_c) = RA[j];                       \
+      *reinterpret_cast<float4*>(Bs + ((buf) * WG_BK + s_r + 16 * j) * BN + s_c) = RB[j];                       \
     }                                                                                                           \
   }
+#define WGP_STORE(buf) WGP_STORE_FROM(ra, rb, buf)
 
   const int half = lane >> 5, l31 = lane & 31;
   const float* a_base = As + half * BM + wm * 64 + 2 * l31;   // float2: channels 2 l31, 2 l31 + 1 of the wave's 64
@@ -301,6 +303,65 @@ __global__ __launch_bounds__(512, 2) void tapwgrad_p_kernel(const WgParams p) {
     WGP_SB();
     frag_mfma(av, bv);
     frag_mfma(aw, bw);
+  } else if constexpr (SCHED == 3) {
+    // SCHED 1 with the loads of TWO K-steps in flight (tapgemm's schedule 7): the tile written to LDS in step s was requested in
+    // step s-1 -- a whole K-step (32 MFMAs of this wave, 128 of its SIMD) more cover for an L2 miss, and the barrier makes every
+    // wave wait for the slowest load.  Two staging register sets used alternately, two steps per trip (buffer index and register
+    // set are compile-time constants); a K-step past the item's end loads nothing (every row fails `m < it.m1`: zero fill).
+    float2 av[4], aw[4];
+    float bv[4], bw[4];
+    float4 ra1[2], rb1[2];
+    WGP_LOAD();                                   // step 0
+    WGP_LOAD_INTO(ra1, rb1);                      // step 1
+    WGP_STORE(0);
+    __syncthreads();
+    frag_load(0, 0, av, bv);
+#define WGP_DSTEP(CUR, LOADS, SA, SB_)                                                                           \
+    {                                                                                                           \
+      LOADS                                                                                                     \
+      WGP_SB();                                                                                                 \
+      frag_load(CUR, 1, aw, bw);                                                                                \
+      WGP_SB();                                                                                                 \
+      frag_mfma(av, bv);                                                                                        \
+      WGP_SB();                                                                                                 \
+      frag_load(CUR, 2, av, bv);                                                                                \
+      WGP_SB();                                                                                                 \
+      frag_mfma(aw, bw);                                                                                        \
+      WGP_SB();                                                                                                 \
+      WGP_STORE_FROM(SA, SB_, (CUR) ^ 1);                                                                       \
+      WGP_SB();                                                                                                 \
+      frag_load(CUR, 3, aw, bw);                                                                                \
+      WGP_SB();                                                                                                 \
+      frag_mfma(av, bv);                                                                                        \
+      WGP_SB();                                                                                                 \
+      __syncthreads();                                                                                          \
+      frag_load((CUR) ^ 1, 0, av, bv);                                                                          \
+      WGP_SB();                                                                                                 \
+      frag_mfma(aw, bw);                                                                                        \
+      WGP_SB();                                                                                                 \
+    }
+    int s = 0, cur = 0;
+    for (; s + 2 < nks; s += 2) {
+      WGP_DSTEP(0, WGP_LOAD();, ra1, rb1)
+      WGP_DSTEP(1, WGP_LOAD_INTO(ra1, rb1);, ra, rb)
+    }
+    if (s + 1 < nks) {                            // two tiles left: s in buffer 0, s+1 in (ra1, rb1)
+      WGP_DSTEP(0, , ra1, rb1)
+      cur = 1;
+    }
+#undef WGP_DSTEP
+    frag_load(cur, 1, aw, bw);
+    WGP_SB();
+    frag_mfma(av, bv);
+    WGP_SB();
+    frag_load(cur, 2, av, bv);
+    WGP_SB();
+    frag_mfma(aw, bw);
+    WGP_SB();
+    frag_load(cur, 3, aw, bw);
+    WGP_SB();
+    frag_mfma(av, bv);
+    frag_mfma(aw, bw);
   } else {
     // three fragment buffers, the loop rotated so that NO LDS read is pending at the back edge (the barrier's lgkmcnt(0) has
     // drained them): a step opens with the reads of its groups 0 and 1, then issues the next tile's global loads and computes
@@ -341,6 +402,8 @@ __global__ __launch_bounds__(512, 2) void tapwgrad_p_kernel(const WgParams p) {
 #undef WGP_SB
 #undef WGP_LOAD
 #undef WGP_STORE
+#undef WGP_LOAD_INTO
+#undef WGP_STORE_FROM
 
   // partial[split][tap][co][ci]; MFMA C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); block e holds the wave's
   // channels 2 row + e
@@ -381,16 +444,19 @@ hipError_t launch_tapwgrad(int cfg, const WgParams& p, int nitems, hipStream_t s
     case WG_128x32: return launch_wg<128, 32, 4, 1>(p, nitems, s);
     case WG_128x128W8: return launch_wg<128, 128, 2, 4>(p, nitems, s);
     case WG_128x128P:
-    case WG_128x128P2: {
+    case WG_128x128P2:
+    case WG_128x128P3: {
       static bool attr_set = false;
       const size_t lds = (size_t)2 * WG_BK * (128 + 128) * sizeof(float);
       if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tapwgrad_p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(tapwgrad_p_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(tapwgrad_p_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
       }
       if (cfg == WG_128x128P) hipLaunchKernelGGL(tapwgrad_p_kernel<1>, dim3(nitems), dim3(512), lds, s, p);
+      else if (cfg == WG_128x128P3) hipLaunchKernelGGL(tapwgrad_p_kernel<3>, dim3(nitems), dim3(512), lds, s, p);
       else hipLaunchKernelGGL(tapwgrad_p_kernel<2>, dim3(nitems), dim3(512), lds, s, p);
       return hipGetLastError();
     }

@@ -755,7 +755,8 @@ def test_round6_weight_paths_are_bitwise_the_round5_ones(env, kind, cin, cout, h
         dy = to_nhwc(rs.randn(n, cout, oh, oh).astype(np.float32))
         W = (rs.randn(*((cout, cin, 5, 5) if kind == "conv" else (cin, cout, 5, 5))) * 0.1).astype(np.float32)
     outs = []
-    for opts in ("wg_pipe=0,wg_reduce_tiled=0,pack_tiled=0", "wg_pipe=1,wg_reduce_tiled=1,pack_tiled=1", "wg_pipe=2,wg_reduce_tiled=1,pack_tiled=1"):
+    for opts in ("wg_pipe=0,wg_reduce_tiled=0,pack_tiled=0", "wg_pipe=1,wg_reduce_tiled=1,pack_tiled=1", "wg_pipe=2,wg_reduce_tiled=1,pack_tiled=1",
+                 "wg_pipe=3,wg_reduce_tiled=1,pack_tiled=1,tg_variant=7"):   # two K-steps of loads in flight, both GEMM families
         monkeypatch.setenv("IAN_OPTS", opts)
         layer = T.Layer(lib, K, cin, cout, h, h) if not kind.startswith("dense") else T.Layer(lib, K, cin, cout, **dense_kw)
         params = [torch.from_numpy(W.ravel()).cuda()]
