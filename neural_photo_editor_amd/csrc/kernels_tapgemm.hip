@@ -88,6 +88,32 @@ __device__ __forceinline__ float epilogue_value(const TgEpilogue& e, float acc, 
 
 constexpr int TG_LDS = 36;  // row stride in floats (32 + 4 pad)
 
+#ifdef IAN_ABLATION
+// libian_ablation.so only: the shader clock tapgemm actually runs at.  Workgroup 0 of every launch adds the shader-clock cycles
+// (s_memtime) and the constant 100 MHz ticks (s_memrealtime) between its first instruction and the end of its K loop; their ratio
+// over a run is the average core clock under THIS load -- the part lowers it under sustained fp32-MFMA work, and a kernel at the
+// power limit cannot be told from one with an idle matrix pipe by its time alone (scripts/exp/tg_clock.py).
+__device__ unsigned long long g_tg_clk[2];
+extern "C" int ian_debug_tg_clock(unsigned long long* out2, int reset) {
+  unsigned long long v[2] = {0, 0};
+  if (out2) {
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_tg_clk), sizeof v) != hipSuccess) return -1;
+    out2[0] = v[0];
+    out2[1] = v[1];
+  }
+  if (reset) {
+    v[0] = v[1] = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tg_clk), v, sizeof v) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#define TG_CLK_BEGIN() unsigned long long clk_c0 = 0, clk_r0 = 0; const bool clk_me = blockIdx.x == 0 && threadIdx.x == 0; if (clk_me) { clk_c0 = clock64(); clk_r0 = wall_clock64(); }
+#define TG_CLK_END() if (clk_me) { atomicAdd(&g_tg_clk[0], (unsigned long long)clock64() - clk_c0); atomicAdd(&g_tg_clk[1], (unsigned long long)wall_clock64() - clk_r0); }
+#else
+#define TG_CLK_BEGIN()
+#define TG_CLK_END()
+#endif
+
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
   float4 r;
@@ -333,6 +359,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
   float* As = smem;                    // [2][BM][36]
   float* Bs = smem + 2 * BM * TG_LDS;  // [2][BN][36]
 
+  TG_CLK_BEGIN();
   const TgItem it = p.items[blockIdx.x];
   if (it.ks0 >= it.ks1) return;  // padding item
   const TgClass cl = p.classes[it.cls];
@@ -499,68 +526,105 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
       tg_frag_mfma<FM, FN>(aw, bw, acc);
     }
 #undef TG_DMA_TILE
-  } else if (VAR != 4 && VAR != 7 && VAR != 8 && VAR != 9) {
+  } else if (VAR != 4 && VAR != 7 && VAR != 8 && !(VAR >= 17 && VAR <= 25)) {
   TG_LOAD_TILE();
   TG_STORE_TILE(0);
   __syncthreads();
   }
   if (DMA) {
-  } else if (VAR == 7 || VAR == 9) {
-    // VAR 9 (experiment): VAR 7 with the wave's priority raised while it issues a group of MFMAs (s_setprio 2 / 0)
-#define TG_PRIO(x) if (VAR == 9) __builtin_amdgcn_s_setprio(x)
-    // ---- VAR 7 (round 6): the rotated schedule of VAR 2 with the loads of TWO K-steps in flight.  In VAR 2 the tile of step s+1 is
-    // requested at the top of step s and written to LDS after the second k group: 16-32 of the wave's own MFMAs (1-2 thousand
-    // cycles of its own, 4-8 thousand with the SIMD's other waves) cover an L2 hit but not a miss to the Infinity Cache / HBM under
-    // load, and the barrier makes every wave of the workgroup wait for the slowest load.  Here the tile written in step s was
-    // requested in step s-1: a whole K-step more of cover, for A_CH + B_CH more staging registers (two sets, used alternately: the
-    // loop body is unrolled by two so that their names are static).  Branch-free past the item's end (TG_LOAD_LIVE_INTO).
+  } else if (VAR == 7 || (VAR >= 17 && VAR <= 25)) {
+    // ---- VAR 7 (round 6) = the production schedule: the rotated schedule of VAR 2 with
+    //  (a) the loads of TWO K-steps in flight.  In VAR 2 the tile of step s+1 is requested at the top of step s and written to LDS
+    //      after the second k group: the barrier makes every wave of the workgroup wait for the slowest load.  Here the tile written
+    //      in step s was requested in step s-1, into the second of two staging register sets (the loop is unrolled by two so that LDS
+    //      buffer and register set are compile-time constants); steps that request nothing are peeled off the end, so no load is
+    //      ever issued past the item;
+    //  (b) NO vector arithmetic per K-step.  Timing-only ablations of (a) (17 .. 25 below, scripts/exp/tg_ablate7.py) put 5.5 % of the
+    //      batch-64 step on the tap fetch + the ~20 VALU instructions that built the load offsets every K-step -- more than the loads
+    //      themselves (2.4 %), the LDS stores (1.5 %), the barrier (0.2 %) or the fragment reads (0): a VALU instruction of ANY wave
+    //      takes its issue cycles from the matrix pipe of its SIMD.  The bounds test and pixel offset of a tile row depend on the TAP
+    //      only, so they are computed once per tap into a_vo[] (kpt = Cin / 32 K-steps apart; an out-of-image row gets TG_OOB), and
+    //      the channel chunk of the step travels in the scalar offset of the buffer instruction.
+    // VAR 17 .. 23 (libian_ablation.so): TIMING-ONLY ablations (results are wrong) -- without the global loads and LDS stores (17), without
+    // the barrier (18), without the fragment reads (19), 17 + 18 (20), all three (21), loads issued and awaited but nothing written to LDS
+    // (22), the LDS stores alone (23).  24 / 25 were ablations of the old per-step addressing (loads folded into a 4 KB window: -1.5 %;
+    // address arithmetic kept, loads dropped: +5.5 % over 17), recorded in docs/MEASURED_NEGATIVES.md.
     // Same MFMA order -> same bits as 1 / 2 / 4 / 6.
+    constexpr bool NOLOAD = VAR == 17 || VAR == 20 || VAR == 21 || VAR == 23, NOBAR = VAR == 18 || VAR == 20 || VAR == 21, NOFRAG = VAR == 19 || VAR == 21;
+    constexpr bool NOSTORE = VAR == 17 || VAR == 20 || VAR == 21 || VAR == 22, TOUCH = VAR == 22;
+    constexpr unsigned TG_OOB = 0xFFFF0000u;          // + a scalar offset < 64 KB stays beyond every extent the host admits (ian_rt_exec.inc)
     float4 ra1[A_CH], rb1[B_CH];
     float4 av[FM], bv[FN], aw[FM], bw[FN];
-    TG_LOAD_TILE();                                   // step 0
-    TG_LOAD_LIVE_INTO(ra1, rb1, nks > 1);             // step 1
+    unsigned a_vo[A_CH];                              // byte offset of (tile row j, current tap, channel 0), or TG_OOB
+    unsigned w_so = 0;                                // byte offset of the current tap's weight slab (wave-uniform)
+#define TG_TAP_SETUP()                                                                                   \
+  {                                                                                                      \
+    const TgTap tp = p.taps[cl.tap0 + min(tap, cl.ntaps - 1)];                                           \
+    const unsigned toff = (unsigned)(((tp.dy * p.IW + tp.dx) * p.Cin) * 4);                              \
+    _Pragma("unroll") for (int j = 0; j < A_CH; ++j) {                                                   \
+      const int iy = a_iy0[j] + tp.dy, ix = a_ix0[j] + tp.dx;                                            \
+      const bool ok = ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);                 \
+      a_vo[j] = ok ? a_off[j] + toff : TG_OOB;                                                           \
+    }                                                                                                    \
+    w_so = w_cls + (unsigned)tap * slab_bytes;                                                           \
+  }
+#define TG_LOAD7(RA, RB)                                                                                 \
+  {                                                                                                      \
+    const unsigned so = (unsigned)(cstep << 7);                                                          \
+    _Pragma("unroll") for (int j = 0; j < A_CH; ++j) RA[j] = buf_load4(xrsrc, a_vo[j], so);              \
+    _Pragma("unroll") for (int j = 0; j < B_CH; ++j) RB[j] = buf_load4(wrsrc, w_row + j * w_rstep, w_so + so); \
+    if (++cstep == kpt) {                             /* next tap: its row offsets, a whole K-step before they are used */ \
+      cstep = 0;                                                                                         \
+      ++tap;                                                                                             \
+      TG_TAP_SETUP()                                                                                     \
+    }                                                                                                    \
+  }
+    TG_TAP_SETUP()
+    TG_LOAD7(ra, rb)                                  // step 0
+    if (nks > 1) TG_LOAD7(ra1, rb1)                   // step 1
     TG_STORE_TILE(0);
     __syncthreads();
     tg_frag_load<FM, FN>(a_base, b_base, 0, av, bv);
+    if (NOFRAG) tg_frag_load<FM, FN>(a_base, b_base, 1, aw, bw);
     // invariant at the top of the loop: tile s is in LDS buffer 0, tile s+1 in (ra1, rb1) -- requested, maybe still in flight --,
-    // (ra, rb) free.  Two steps per trip, so the LDS buffer index and the register set of each step are compile-time constants.
+    // (ra, rb) free
 #define TG_DSTEP(CUR, LOADS, SA, SB)                                                                               \
     {                                                                                                              \
       const float* a_s = a_base + (CUR) * BM * TG_LDS;                                                             \
       const float* b_s = b_base + (CUR) * BN * TG_LDS;                                                             \
-      LOADS                                                                                                        \
+      if (!NOLOAD) { LOADS }                                                                                       \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
-      tg_frag_load<FM, FN>(a_s, b_s, 1, aw, bw);                                                                   \
-      TG_PRIO(2);                                                                                                  \
+      if (!NOFRAG) tg_frag_load<FM, FN>(a_s, b_s, 1, aw, bw);                                                      \
       tg_frag_mfma<FM, FN>(av, bv, acc);               /* kk 0 */                                                  \
-      tg_frag_load<FM, FN>(a_s, b_s, 2, av, bv);                                                                   \
+      if (!NOFRAG) tg_frag_load<FM, FN>(a_s, b_s, 2, av, bv);                                                      \
       tg_frag_mfma<FM, FN>(aw, bw, acc);               /* kk 1 */                                                  \
-      TG_PRIO(0);                                                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
-      TG_STORE_FROM(SA, SB, (CUR) ^ 1);                /* the next tile, requested a whole K-step ago */           \
+      if (!NOSTORE) TG_STORE_FROM(SA, SB, (CUR) ^ 1);  /* the next tile, requested a whole K-step ago */           \
+      if (TOUCH) { _Pragma("unroll") for (int j_ = 0; j_ < A_CH; ++j_) asm volatile("" :: "v"(SA[j_].x)); _Pragma("unroll") for (int j_ = 0; j_ < B_CH; ++j_) asm volatile("" :: "v"(SB[j_].x)); } \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
-      tg_frag_load<FM, FN>(a_s, b_s, 3, aw, bw);                                                                   \
-      TG_PRIO(2);                                                                                                  \
+      if (!NOFRAG) tg_frag_load<FM, FN>(a_s, b_s, 3, aw, bw);                                                      \
       tg_frag_mfma<FM, FN>(av, bv, acc);               /* kk 2 */                                                  \
-      TG_PRIO(0);                                                                                                  \
-      __syncthreads();                                                                                             \
-      tg_frag_load<FM, FN>(a_base + ((CUR) ^ 1) * BM * TG_LDS, b_base + ((CUR) ^ 1) * BN * TG_LDS, 0, av, bv);     \
+      if (!NOBAR) __syncthreads();                                                                                 \
+      if (!NOFRAG) tg_frag_load<FM, FN>(a_base + ((CUR) ^ 1) * BM * TG_LDS, b_base + ((CUR) ^ 1) * BN * TG_LDS, 0, av, bv); \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
-      TG_PRIO(2);                                                                                                  \
       tg_frag_mfma<FM, FN>(aw, bw, acc);               /* kk 3 of the previous buffer */                           \
-      TG_PRIO(0);                                                                                                  \
     }
     int s = 0;
-    for (; s + 2 < nks; s += 2) {
-      TG_DSTEP(0, TG_LOAD_TILE();, ra1, rb1)                          // tile s+2 exists
-      TG_DSTEP(1, TG_LOAD_LIVE_INTO(ra1, rb1, s + 3 < nks);, ra, rb)
+    for (; s + 3 < nks; s += 2) {                                     // tiles s+2 and s+3 exist
+      TG_DSTEP(0, TG_LOAD7(ra, rb), ra1, rb1)
+      TG_DSTEP(1, TG_LOAD7(ra1, rb1), ra, rb)
     }
-    if (s + 1 < nks) {                                                // two tiles left: s in buffer 0, s+1 in (ra1, rb1)
+    if (s + 2 < nks) {                                                // three tiles left: s in buffer 0, s+1 in (ra1, rb1), s+2 to request
+      TG_DSTEP(0, TG_LOAD7(ra, rb), ra1, rb1)
+      TG_DSTEP(1, , ra, rb)
+      cur = 0;
+    } else if (s + 1 < nks) {                                         // two tiles left
       TG_DSTEP(0, , ra1, rb1)
       cur = 1;
     }
 #undef TG_DSTEP
-#undef TG_PRIO
+#undef TG_LOAD7
+#undef TG_TAP_SETUP
     {
       const float* a_s = a_base + cur * BM * TG_LDS;
       const float* b_s = b_base + cur * BN * TG_LDS;
@@ -773,6 +837,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
 #undef TG_STORE_TILE
 #undef TG_LOAD_INTO
 #undef TG_LOAD_LIVE_INTO
+  TG_CLK_END();
 #undef TG_STORE_FROM
 
   // ---- epilogue. C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
@@ -1391,7 +1456,13 @@ static hipError_t launch_cfg(const TgParams& p, int nitems, hipStream_t s) {
                       // The shipped library contains none of them and rejects the option values.
     case 0: return launch_var<BM, BN, WM, WN, 0>(p, nitems, s);
     case 8: if constexpr (BM * BN <= 128 * 64) return launch_var<BM, BN, WM, WN, 8>(p, nitems, s); else return launch_var<BM, BN, WM, WN, 7>(p, nitems, s);   // three K-steps in flight (small tiles): measured no better than 7
-    case 9: return launch_var<BM, BN, WM, WN, 9>(p, nitems, s);   // 7 + s_setprio around the MFMA groups (experiment)
+    case 17: return launch_var<BM, BN, WM, WN, 17>(p, nitems, s);   // 17 .. 21: timing-only ablations of schedule 7 (WRONG results)
+    case 18: return launch_var<BM, BN, WM, WN, 18>(p, nitems, s);
+    case 19: return launch_var<BM, BN, WM, WN, 19>(p, nitems, s);
+    case 20: return launch_var<BM, BN, WM, WN, 20>(p, nitems, s);
+    case 21: return launch_var<BM, BN, WM, WN, 21>(p, nitems, s);
+    case 22: return launch_var<BM, BN, WM, WN, 22>(p, nitems, s);
+    case 23: return launch_var<BM, BN, WM, WN, 23>(p, nitems, s);
     case 3: return launch_var<BM, BN, WM, WN, 3>(p, nitems, s);
     case 10: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 10>(p, nitems, s); return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);
     case 11: if (BM == 64 && BN == 64) return launch_var<64, 64, 2, 2, 11>(p, nitems, s); return launch_var<BM, BN, WM, WN, 2>(p, nitems, s);
