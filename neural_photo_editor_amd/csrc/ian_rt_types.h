@@ -137,6 +137,7 @@ struct Options {
                                      // 44.28 / 44.03 k reconstructions/s without vs 44.13 / 44.01 k with the candidate: no gain, 25 % more tuning time
   int tg_reduce_kp = 4;              // split-K reduce: lanes sharing one output element's slabs when a tile has >= 8 slabs
   int wg_w8 = 1;                     // tapwgrad: 8-wave 128x128 workgroups (16 waves per CU instead of 8)
+  int wg_reduce_tci = 16;            // tiled split reduce / repack: channels per tile row (16: 64-byte runs; 32: 128-byte runs, half the filters per tile)
   int wg_pipe = 3;                   // tapwgrad: the software-pipelined K loop of the 8-wave tile (tapwgrad_p_kernel; 0 = the compiler-scheduled loop, bitwise the same)
   int zbuild_rows = 1;               // head6 backward: Z built a pixel row at a time through LDS (head6_zbuild_rows_kernel; 0 = per (pixel, tap), same bytes)
   int pack_tiled = 1;                // training layers repack their slabs after an update through LDS tiles (pack_tiled_kernel; 0 = the gather, same bytes)

@@ -231,6 +231,40 @@ __global__ __launch_bounds__(512, 2) void tapwgrad_p_kernel(const WgParams p) {
     }                                                                                                           \
   }
 #define WGP_STORE(buf) WGP_STORE_FROM(ra, rb, buf)
+  // SCHED 3's loads (round 6): the pixel index of a tile row is m = mbase + r with mbase a multiple of 32 and r < 32, and the map extents are
+  // powers of two -- so image, row and column of m are the SUMS of their parts in mbase (wave-uniform: scalar arithmetic) and in r (a
+  // thread constant), without carries, and every offset is linear in them.  The old form rebuilt both offsets from m with six integer
+  // multiplies (quarter rate) and ~20 further vector instructions per row and K-step; a vector instruction of any wave takes its issue
+  // cycles from the SIMD's matrix pipe (tapgemm schedule 7 measured 5.5 % of a whole step for a third of this arithmetic).  Now per row and
+  // step: the bounds tests against the uniform part (adds + compares, no multiply) and one add per offset.
+  unsigned a_vt[2], b_vt[2];
+  int t_y[2], t_x[2], t_r[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = s_r + 16 * j;
+    const int n_t = r >> p.qhw_shift, rem_t = r & qhw_mask;
+    const int qy_t = rem_t >> p.qw_shift, qx_t = rem_t & qw_mask;
+    t_r[j] = r;
+    t_y[j] = qy_t * p.si + by;
+    t_x[j] = qx_t * p.si + bx;
+    a_vt[j] = (unsigned)((((n_t * p.OH + qy_t * p.so + y0) * p.OW + qx_t * p.so + x0) * p.dy_stride + a_cbase) * 4);
+    b_vt[j] = (unsigned)((((n_t * p.IH + t_y[j]) * p.IW + t_x[j]) * p.Cin + b_cbase) * 4);
+  }
+#define WGP_LOADU_INTO(RA, RB)                                                                                  \
+  {                                                                                                             \
+    const int n_u = mbase >> p.qhw_shift, rem_u = mbase & qhw_mask;                                             \
+    const int qy_u = rem_u >> p.qw_shift, qx_u = rem_u & qw_mask;                                               \
+    const unsigned a_su = (unsigned)((((n_u * p.OH + qy_u * p.so) * p.OW + qx_u * p.so) * p.dy_stride) * 4);    \
+    const unsigned b_su = (unsigned)((((n_u * p.IH + qy_u * p.si) * p.IW + qx_u * p.si) * p.Cin) * 4);          \
+    const int uy = qy_u * p.si, ux = qx_u * p.si, lim = it.m1 - mbase;                                          \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                             \
+      const bool in = t_r[j] < lim;                                                                             \
+      RA[j] = wg_load4(yrsrc, (a_col_ok & in) ? a_vt[j] + a_su : 0xFFFFFFF0u);                                  \
+      const bool okb = b_col_ok & in & ((unsigned)(t_y[j] + uy) < (unsigned)p.IH) & ((unsigned)(t_x[j] + ux) < (unsigned)p.IW); \
+      RB[j] = wg_load4(xrsrc, okb ? b_vt[j] + b_su : 0xFFFFFFF0u);                                              \
+    }                                                                                                           \
+    mbase += WG_BK;                                                                                             \
+  }
 
   const int half = lane >> 5, l31 = lane & 31;
   const float* a_base = As + half * BM + wm * 64 + 2 * l31;   // float2: channels 2 l31, 2 l31 + 1 of the wave's 64
@@ -311,8 +345,8 @@ __global__ __launch_bounds__(512, 2) void tapwgrad_p_kernel(const WgParams p) {
     float2 av[4], aw[4];
     float bv[4], bw[4];
     float4 ra1[2], rb1[2];
-    WGP_LOAD();                                   // step 0
-    WGP_LOAD_INTO(ra1, rb1);                      // step 1
+    WGP_LOADU_INTO(ra, rb);                       // step 0
+    WGP_LOADU_INTO(ra1, rb1);                     // step 1
     WGP_STORE(0);
     __syncthreads();
     frag_load(0, 0, av, bv);
@@ -342,8 +376,8 @@ __global__ __launch_bounds__(512, 2) void tapwgrad_p_kernel(const WgParams p) {
     }
     int s = 0, cur = 0;
     for (; s + 2 < nks; s += 2) {
-      WGP_DSTEP(0, WGP_LOAD();, ra1, rb1)
-      WGP_DSTEP(1, WGP_LOAD_INTO(ra1, rb1);, ra, rb)
+      WGP_DSTEP(0, WGP_LOADU_INTO(ra, rb);, ra1, rb1)
+      WGP_DSTEP(1, WGP_LOADU_INTO(ra1, rb1);, ra, rb)
     }
     if (s + 1 < nks) {                            // two tiles left: s in buffer 0, s+1 in (ra1, rb1)
       WGP_DSTEP(0, , ra1, rb1)
@@ -404,6 +438,7 @@ __global__ __launch_bounds__(512, 2) void tapwgrad_p_kernel(const WgParams p) {
 #undef WGP_STORE
 #undef WGP_LOAD_INTO
 #undef WGP_STORE_FROM
+#undef WGP_LOADU_INTO
 
   // partial[split][tap][co][ci]; MFMA C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); block e holds the wave's
   // channels 2 row + e

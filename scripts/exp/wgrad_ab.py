@@ -12,7 +12,7 @@ n = int(os.environ.get("B", "128"))
 reps = int(os.environ.get("REPS", "10"))
 lib = load_train_library()
 PEAK = 157.3
-VARIANTS = [("base", "wg_pipe=0,wg_reduce_tiled=0"), ("p1", "wg_pipe=1,wg_reduce_tiled=1"), ("p2", "wg_pipe=2,wg_reduce_tiled=1"), ("p3", "wg_pipe=3,wg_reduce_tiled=1"),
+VARIANTS = [("base", "wg_pipe=0,wg_reduce_tiled=0"), ("p1", "wg_pipe=1,wg_reduce_tiled=1"), ("p2", "wg_pipe=2,wg_reduce_tiled=1"), ("p3", "wg_pipe=3,wg_reduce_tiled=1"), ("p3_tci32", "wg_pipe=3,wg_reduce_tiled=1,wg_reduce_tci=32"),
             ("p1_t512", "wg_pipe=1,wg_reduce_tiled=1,wg_target_items=512"), ("p1_t1536", "wg_pipe=1,wg_reduce_tiled=1,wg_target_items=1536")]
 
 
