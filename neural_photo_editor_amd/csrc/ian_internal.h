@@ -90,6 +90,8 @@ struct TgParams {
                               // 2: atomic accumulation into `raw`, epilogue by the last arriver (kernels_tapgemm.hip)
   const unsigned short* wsplit;  // tapgemm_bf16x3_kernel: the weights pre-split into a bf16 hi plane followed by a lo plane (or nullptr)
   int bf_sched;                  // ... and its K-loop schedule (0..2)
+  int noepi;                     // libian_ablation.so: skip everything behind the K loop (timing-only)
+  unsigned y_bytes;              // extent of y (and of res / yfwd, same layout) for the buffer-descriptor epilogue; 0: above the descriptor range, general epilogue
 };
 
 struct TgReduceParams {

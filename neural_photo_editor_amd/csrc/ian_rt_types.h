@@ -133,6 +133,8 @@ struct Options {
   int tg_tune_model = 1;             // 1: autotune also times the split limits a longest-first model of the launch ranks best (ian_rt_autotune.inc)
   int tg_tune_final = 6;             // autotune: the N fastest candidates of the first pass (5 launches each) are timed again in 3 interleaved rounds of 12 launches; 0 = first pass decides
   int tg_variant_force = -1;         // >= 0: every tapgemm launch takes this K-loop schedule, also over an autotuned choice (A/B and ablation timing: scripts/exp/tg_ablate7.py)
+  int tg_noepi = 0;                  // libian_ablation.so only: tapgemm returns right after its K loop (timing-only ablation, wrong results)
+  int tg_fast_epilogue = 1;          // tapgemm: the per-row / per-column epilogue (tg_store_fast) where it applies; 0 = the general form everywhere (A/B, bitwise the same)
   int tg_tune_pin = 0;               // 1: autotune also times K-loop schedule 6 (schedule 2 with its fragment reads pinned; kernels_tapgemm.hip).  OFF: measured,
                                      // 44.28 / 44.03 k reconstructions/s without vs 44.13 / 44.01 k with the candidate: no gain, 25 % more tuning time
   int tg_reduce_kp = 4;              // split-K reduce: lanes sharing one output element's slabs when a tile has >= 8 slabs

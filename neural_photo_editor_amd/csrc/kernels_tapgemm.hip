@@ -194,10 +194,71 @@ __device__ __forceinline__ void tg_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds
 #endif
 }
 
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0));
+}
+
+// The epilogue of a tile whose columns all exist and whose affine is per channel (round 6).  Behind the K loop every wave of a SIMD runs
+// this at the same time with no MFMA left to hide it: a timing-only build that returns after the K loop (tg_noepi) put 5 % of the batch-64
+// step behind it, and the general form below spends ~40 vector instructions per stored value (64-bit addresses, the per-value scale /
+// shift loads, the runtime `% scale_period`).  Here: scale / shift once per column, one 32-bit byte offset per tile ROW (an invalid row gets
+// an out-of-range offset: the hardware drops its stores and returns 0 for its loads), the column of block j as the instruction's immediate
+// offset.  The arithmetic per value is epilogue_value's, expression for expression.
+constexpr unsigned TG_OOB_Y = 0xFFFF0000u;
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void tg_store_fast(const TgParams& p, const TgItem& it, const TgClass& cl,
+                                              f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wm, int wn, int lane) {
+  constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
+  const TgEpilogue& e = p.epi;
+  const int qhw_mask = (1 << p.qhw_shift) - 1, qw_mask = (1 << p.qw_shift) - 1;
+  const int rhalf = 4 * (lane >> 5);
+  const int c0 = it.n0 + wn * (BN / WN) + (lane & 31);
+  float sc[FN], sh[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    sc[j] = e.scale ? e.scale[c0 + j * 32] : 1.f;
+    sh[j] = e.shift ? e.shift[c0 + j * 32] : 0.f;
+  }
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.res ? e.res : p.y), 0, p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.yfwd ? e.yfwd : p.y), 0, p.y_bytes, 0x00020000);
+  const unsigned colb = (unsigned)c0 * 4u, ystr = (unsigned)p.y_stride * 4u;
+  const bool fwd = e.mode == TG_EPI_FWD, has_res = e.res != nullptr, has_yf = e.yfwd != nullptr;
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = it.m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+      const int n = m >> p.qhw_shift, rem = m & qhw_mask;
+      const int oy = (rem >> p.qw_shift) * p.so + cl.py, ox = (rem & qw_mask) * p.so + cl.px;
+      const unsigned pix = (unsigned)((n * p.OH + oy) * p.OW + ox);
+      const unsigned off = (m < p.M) ? pix * ystr + colb : TG_OOB_Y;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const unsigned o = off + (unsigned)(j * 128);
+        float a = acc[i][j][r], v;
+        if (fwd) {
+          if (has_res) a += buf_load1(rr, o);
+          v = act_apply_rt(a * sc[j] + sh[j], e.act);
+        } else {
+          const float yf = has_yf ? buf_load1(fr, o) : 0.f;
+          float g = a * act_grad_rt(yf, e.act) * sc[j];
+          if (has_res) g += buf_load1(rr, o);
+          v = g;
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, o, 0, 0);
+      }
+    }
+}
+
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void tg_store(const TgParams& p, const TgItem& it, const TgClass& cl,
                                          f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wm, int wn, int lane) {
   constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
+  if (p.y_bytes != 0 && p.epi.scale_period == 0 && it.n0 + BN <= p.Cout) {   // == every column of the tile exists, per-channel affine
+    tg_store_fast<BM, BN, WM, WN>(p, it, cl, acc, wm, wn, lane);
+    return;
+  }
   const int qhw_mask = (1 << p.qhw_shift) - 1, qw_mask = (1 << p.qw_shift) - 1;
   const int col_l = lane & 31;
   const int rhalf = 4 * (lane >> 5);
@@ -840,6 +901,14 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
   TG_CLK_END();
 #undef TG_STORE_FROM
 
+#ifdef IAN_ABLATION
+  if (p.noepi) {   // timing-only (tg_ablate7.py): what everything behind the K loop costs -- one value per lane keeps the accumulators live
+    float sacc = 0.f;
+    for (int i = 0; i < FM; ++i) for (int j = 0; j < FN; ++j) for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (sacc == 12345.678f) p.y[0] = sacc;
+    return;
+  }
+#endif
   // ---- epilogue. C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
   if (it.slab >= 0) {
 #ifdef IAN_NO_TG_FUSE   // libian_nofuse.so (IAN_NOFUSE_BUILD=1, scripts/exp/tgfuse_ab.py): the round-5 in-launch combine epilogue compiled OUT

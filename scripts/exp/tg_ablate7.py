@@ -27,7 +27,17 @@ for rep in range(3):
         e1.record(); torch.cuda.synchronize()
         res.setdefault(v, []).append(e0.elapsed_time(e1) / 100)
 h.set_option("tg_variant_force", -1)
-names = {7: "schedule 7 (production)", 2: "schedule 2 (round 5)", 17: "no global loads / LDS stores", 18: "no barrier", 19: "no fragment reads", 20: "no loads, no barrier", 21: "MFMAs + control flow only", 22: "loads issued and awaited, no LDS stores", 23: "LDS stores only (no loads)"}
+for rep in range(3):   # the production schedule without anything behind the K loop (no epilogue arithmetic, no stores; reduce launches still run)
+    h.set_option("tg_noepi", 1)
+    for _ in range(10): step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100): step()
+    e1.record(); torch.cuda.synchronize()
+    res.setdefault(99, []).append(e0.elapsed_time(e1) / 100)
+h.set_option("tg_noepi", 0)
+VARS = VARS + [99]
+names = {99: "schedule 7, tapgemm returns after its K loop", 7: "schedule 7 (production)", 2: "schedule 2 (round 5)", 17: "no global loads / LDS stores", 18: "no barrier", 19: "no fragment reads", 20: "no loads, no barrier", 21: "MFMAs + control flow only", 22: "loads issued and awaited, no LDS stores", 23: "LDS stores only (no loads)"}
 outd = {"arch": arch, "batch": B, "ms_per_step": {names[v]: float(np.median(res[v])) for v in VARS}, "runs": {names[v]: res[v] for v in VARS}}
 for v in VARS: print("%-32s %s  median %.4f ms" % (names[v], " ".join("%.4f" % t for t in res[v]), float(np.median(res[v]))))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
