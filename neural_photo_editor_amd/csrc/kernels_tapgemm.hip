@@ -224,14 +224,18 @@ __device__ __forceinline__ void tg_store_fast(const TgParams& p, const TgItem& i
   const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.yfwd ? e.yfwd : p.y), 0, p.y_bytes, 0x00020000);
   const unsigned colb = (unsigned)c0 * 4u, ystr = (unsigned)p.y_stride * 4u;
   const bool fwd = e.mode == TG_EPI_FWD, has_res = e.res != nullptr, has_yf = e.yfwd != nullptr;
+  const bool ident = p.so == 1 && cl.py == 0 && cl.px == 0 && (1 << p.qw_shift) == p.OW && (1 << p.qhw_shift) == p.OH * p.OW;   // wave-uniform
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = it.m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-      const int n = m >> p.qhw_shift, rem = m & qhw_mask;
-      const int oy = (rem >> p.qw_shift) * p.so + cl.py, ox = (rem & qw_mask) * p.so + cl.px;
-      const unsigned pix = (unsigned)((n * p.OH + oy) * p.OW + ox);
+      unsigned pix = (unsigned)m;                    // stride-1 layers whose output map is the tile-row map: the pixel IS the row
+      if (!ident) {
+        const int n = m >> p.qhw_shift, rem = m & qhw_mask;
+        const int oy = (rem >> p.qw_shift) * p.so + cl.py, ox = (rem & qw_mask) * p.so + cl.px;
+        pix = (unsigned)((n * p.OH + oy) * p.OW + ox);
+      }
       const unsigned off = (m < p.M) ? pix * ystr + colb : TG_OOB_Y;
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
