@@ -20,13 +20,20 @@ struct TgClass {
   int py, px;       // output parity offset
   long long w_off;  // float offset of this class's first weight slab; slab t at w_off + t*CoutPad*Cin
 };
-struct TgItem {  // one workgroup's job (host-built table, 32 B)
+struct TgItem {  // one workgroup's job (host-built table, 64 B = one s_load_dwordx16)
   int cls, m0, n0;
   int ks0, ks1;  // K-step range [ks0,ks1) of 32-channel steps over (tap, ci-chunk)
   int slab;      // split-K: slab tile index; -1 = direct epilogue
   int tile;      // split-K: index of the output tile in the TgTile table (fused combine: counter + slab range)
+  // the item's TgClass and the tap its K range starts in, COPIED here (fill_item_class, ian_rt_schedule.inc) so that the kernel's
+  // prologue is one table fetch instead of three dependent ones (item -> class -> tap: ~0.5-1 us each from a cold L2, before the
+  // first operand load can be addressed); the tables stay as they are for the taps after the first and for the split-bf16 kernel
+  int ntaps, tap0, py, px;
+  int dy0, dx0;  // taps[tap0 + ks0 / (Cin / 32)]
   int pad1;
+  long long w_off;
 };
+static_assert(sizeof(TgItem) == 64, "TgItem is fetched as one 64-byte scalar load");
 struct TgTile {  // reduce pass: one output tile
   int cls, m0, n0, slab0, nsplit;
   int py, px;  // the class's output parity offset, copied here so that the reduce pass needs ONE table load, not two dependent ones

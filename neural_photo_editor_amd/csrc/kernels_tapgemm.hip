@@ -427,7 +427,12 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
   TG_CLK_BEGIN();
   const TgItem it = p.items[blockIdx.x];
   if (it.ks0 >= it.ks1) return;  // padding item
-  const TgClass cl = p.classes[it.cls];
+  // the item carries its class and the tap its K range starts in (TgItem, ian_internal.h): ONE table fetch in front of the first
+  // operand load instead of three dependent ones (item -> p.classes[cls] -> p.taps[tap0 + ..])
+  TgClass cl;
+  cl.ntaps = it.ntaps; cl.tap0 = it.tap0; cl.py = it.py; cl.px = it.px; cl.w_off = it.w_off;
+  TgTap tp_first;
+  tp_first.dy = it.dy0; tp_first.dx = it.dx0;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -476,9 +481,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-#define TG_LOAD_INTO(RA, RB)                                                                                 \
+#define TG_LOAD_INTO(RA, RB) TG_LOAD_INTO_TP(RA, RB, p.taps[cl.tap0 + tap])
+#define TG_LOAD_INTO_TP(RA, RB, TP)                                                                      \
   {                                                                                                      \
-    const TgTap tp = p.taps[cl.tap0 + tap];                                                              \
+    const TgTap tp = TP;                                                                                 \
     const unsigned doff = (unsigned)(((tp.dy * p.IW + tp.dx) * p.Cin + (cstep << 5)) * 4);               \
     _Pragma("unroll") for (int j = 0; j < A_CH; ++j) {                                                   \
       const int iy = a_iy0[j] + tp.dy, ix = a_ix0[j] + tp.dx;                                            \
@@ -493,6 +499,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
     }                                                                                                    \
   }
 #define TG_LOAD_TILE() TG_LOAD_INTO(ra, rb)
+#define TG_LOAD_TILE_FIRST() TG_LOAD_INTO_TP(ra, rb, tp_first)   /* the item's first K-step: its tap came with the item */
 // the same loads, BRANCH-FREE past the end of the item: a K-step beyond its range (LIVE false, wave-uniform) addresses out of range and the
 // hardware returns zeros without touching memory, so that a run-ahead loop body stays one basic block (VAR 7)
 #define TG_LOAD_LIVE_INTO(RA, RB, LIVE)                                                                  \
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
     }
 #undef TG_DMA_TILE
   } else if (VAR != 4 && VAR != 7 && VAR != 8 && !(VAR >= 17 && VAR <= 25)) {
-  TG_LOAD_TILE();
+  TG_LOAD_TILE_FIRST();
   TG_STORE_TILE(0);
   __syncthreads();
   }
@@ -622,9 +629,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
     float4 av[FM], bv[FN], aw[FM], bw[FN];
     unsigned a_vo[A_CH];                              // byte offset of (tile row j, current tap, channel 0), or TG_OOB
     unsigned w_so = 0;                                // byte offset of the current tap's weight slab (wave-uniform)
-#define TG_TAP_SETUP()                                                                                   \
+#define TG_TAP_SETUP() TG_TAP_SETUP_TP(p.taps[cl.tap0 + min(tap, cl.ntaps - 1)])
+#define TG_TAP_SETUP_TP(TP)                                                                              \
   {                                                                                                      \
-    const TgTap tp = p.taps[cl.tap0 + min(tap, cl.ntaps - 1)];                                           \
+    const TgTap tp = TP;                                                                                 \
     const unsigned toff = (unsigned)(((tp.dy * p.IW + tp.dx) * p.Cin) * 4);                              \
     _Pragma("unroll") for (int j = 0; j < A_CH; ++j) {                                                   \
       const int iy = a_iy0[j] + tp.dy, ix = a_ix0[j] + tp.dx;                                            \
@@ -644,7 +652,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
       TG_TAP_SETUP()                                                                                     \
     }                                                                                                    \
   }
-    TG_TAP_SETUP()
+    TG_TAP_SETUP_TP(tp_first)
     TG_LOAD7(ra, rb)                                  // step 0
     if (nks > 1) TG_LOAD7(ra1, rb1)                   // step 1
     TG_STORE_TILE(0);
@@ -690,6 +698,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
 #undef TG_DSTEP
 #undef TG_LOAD7
 #undef TG_TAP_SETUP
+#undef TG_TAP_SETUP_TP
     {
       const float* a_s = a_base + cur * BM * TG_LDS;
       const float* b_s = b_base + cur * BN * TG_LDS;
@@ -707,7 +716,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
     // round trip under load (64x64: 16 MFMAs per wave and step, 16 B/clk/CU of operand traffic).  Same MFMA order -> same bits.
     float4 ra1[A_CH], rb1[B_CH], ra2[A_CH], rb2[B_CH];
     float4 av[FM], bv[FN], aw[FM], bw[FN];
-    TG_LOAD_TILE();                                   // step 0
+    TG_LOAD_TILE_FIRST();                             // step 0
     TG_LOAD_LIVE_INTO(ra1, rb1, nks > 1);             // step 1
     TG_LOAD_LIVE_INTO(ra2, rb2, nks > 2);             // step 2
     TG_STORE_TILE(0);
@@ -783,7 +792,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
     // issued three steps ago) and its registers are reloaded at once.  Same MFMA order -> same bits.
     float4 q0a[A_CH], q0b[B_CH], q1a[A_CH], q1b[B_CH], q2a[A_CH], q2b[B_CH];
     int issued = 1;
-    TG_LOAD_TILE();
+    TG_LOAD_TILE_FIRST();
     if (issued < nks) { TG_LOAD_INTO(q0a, q0b); ++issued; }
     if (issued < nks) { TG_LOAD_INTO(q1a, q1b); ++issued; }
     if (issued < nks) { TG_LOAD_INTO(q2a, q2b); ++issued; }
@@ -899,6 +908,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 4) void tapgemm_ke
 #undef TG_PIN
   }
 #undef TG_LOAD_TILE
+#undef TG_LOAD_TILE_FIRST
+#undef TG_LOAD_INTO_TP
 #undef TG_STORE_TILE
 #undef TG_LOAD_INTO
 #undef TG_LOAD_LIVE_INTO

@@ -24,7 +24,9 @@ from neural_photo_editor_amd import IAN, synthetic as O  # noqa: E402
 from neural_photo_editor_amd import lib as L  # noqa: E402
 
 CFG = os.path.join(ROOT, "neural_photo_editor_amd", "configs", "IAN_simple.py")
-NOFUSE = os.path.join(ROOT, "neural_photo_editor_amd", "libian_nofuse.so")
+NOFUSE = os.environ.get("AB_LIB_B") or os.path.join(ROOT, "neural_photo_editor_amd", "libian_nofuse.so")   # AB_LIB_B: any other build of the library (e.g. the previous commit's)
+LABEL_B = os.environ.get("AB_LABEL", "nofuse")
+OUT_NAME = os.environ.get("AB_OUT", "r06_tgfuse_ab.json")
 ROUNDS = int(os.environ.get("AB_ROUNDS", "5"))
 
 
@@ -99,20 +101,20 @@ def main():
             res[k]["step64_ms"].append(dev_ms(h, x64, 64, o64, 100))
             res[k]["b1_recon_ms"].append(dev_ms(h, x1, 1, o1, 200))
             res[k]["brush_p50_ms"].append(brush_ms(models[k]))
-    out = {"what": __doc__.split("\n\n")[0] if False else "in-process A/B of libian.so (A, HEAD) vs libian_nofuse.so (B, -DIAN_NO_TG_FUSE: round-4 small-tile object code); same autotune cache; alternated",
+    out = {"what": __doc__.split("\n\n")[0] if False else ("in-process A/B of libian.so (A, HEAD) vs libian_nofuse.so (B, -DIAN_NO_TG_FUSE: round-4 small-tile object code); same autotune cache; alternated" if LABEL_B == "nofuse" else "in-process A/B of libian.so (A, HEAD) vs %s (B, %s); same autotune cache; alternated" % (os.path.basename(NOFUSE), LABEL_B)),
            "rounds": ROUNDS, "bitwise_equal_batch64_output": same, "samples": res, "median": {}, "B_over_A": {}}
     for w in ("step64_ms", "b1_recon_ms", "brush_p50_ms"):
         ma, mb = float(np.median(res["A"][w])), float(np.median(res["B"][w]))
-        out["median"][w] = {"A_head": ma, "B_nofuse": mb}
+        out["median"][w] = {"A_head": ma, "B_" + LABEL_B: mb}
         out["B_over_A"][w] = mb / ma
-    out["verdict"] = "epilogue costs %.2f %% at batch 64, %.2f %% on the batch-1 reconstruction, %.2f %% on the brush event (positive = HEAD slower than the no-fuse build)" % tuple(
+    out["verdict"] = "HEAD costs %.2f %% at batch 64, %.2f %% on the batch-1 reconstruction, %.2f %% on the brush event (positive = HEAD slower than B)" % tuple(
         100.0 * (1.0 / out["B_over_A"][w] - 1.0) for w in ("step64_ms", "b1_recon_ms", "brush_p50_ms"))
     try:
         out["box"] = L.box_probe(900, 250, stream=st)
     except Exception as exc:  # noqa: BLE001
         out["box"] = {"error": str(exc)}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r06_tgfuse_ab.json"), "w") as fh:
+    with open(os.path.join(ROOT, "gpurun_out", OUT_NAME), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps({k: out[k] for k in ("bitwise_equal_batch64_output", "median", "B_over_A", "verdict", "box")}, indent=1))
 
