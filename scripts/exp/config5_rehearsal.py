@@ -2,7 +2,7 @@
 (SyncBN statistics combined in rank order by the 8-way tree, MinibatchLayer over all 1024 rows -- layers.py:506-520 couples the
 whole minibatch, train_IAN.py:116-149 normalises over it), through ian_train_step's sequencer, against ONE process at batch 1024.
 
-  python scripts/exp/config5_rehearsal.py [world=8] [global_batch=1024]  ->  gpurun_out/r05_config5_rehearsal.json
+  python scripts/exp/config5_rehearsal.py [world=8] [global_batch=1024]  ->  gpurun_out/$REC_NAME (default r06_config5_rehearsal.json)
 
 Part 1 (parity): 8 gloo ranks time-sharing the MI355X (tests/dp_rehearsal.py, the worker of tests/test_gpu_dp.py) vs the single
 process: losses, all three gradient groups per tensor (relative L2), bucket hand-over during backward at the 8-rank plans.
@@ -124,7 +124,7 @@ def main():
     os.environ.pop("IAN_OPTS")                   # part 2 times the production schedules (split-K on, autotuned)
     rec["exact_mode_cost"] = cost_of_exact(world, n)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r05_config5_rehearsal.json"), "w") as fh:
+    with open(os.path.join(ROOT, "gpurun_out", os.environ.get("REC_NAME", "r06_config5_rehearsal.json")), "w") as fh:
         json.dump(rec, fh, indent=1, default=lambda o: float(o) if isinstance(o, (np.floating, float)) else str(o))
     print(json.dumps({k: rec[k] for k in rec if not k.startswith("grad_rel_l2/")}, default=str)[:3000])
     print("worst gradient tensor error %.3g (bar 3e-5): %s" % (worst, "PASS" if worst < 3e-5 else "FAIL"))

@@ -157,6 +157,35 @@ def test_bf16x3_option_is_opt_in_and_inside_the_parity_bar(arch):
         m.close()
 
 
+def test_tune_cache_keeps_the_split_bf16_choices_apart(tmp_path, monkeypatch):
+    """IAN_TUNE_CACHE is shared by every handle of a process tree (the rocprofv3 passes of one profile replay the first run's
+    choices).  A handle in the opt-in tg_bf16x3 mode tunes OTHER kernels on other tiles: its entries carry their own direction key,
+    so it neither replays the exact-fp32 choices (fp32 kernels on every tile the split-bf16 kernel is not instantiated for: the
+    bench line's labelled secondary once read 1.17 instead of 0.66 ms that way) nor overwrites them."""
+    from neural_photo_editor_amd import IAN
+    cache = tmp_path / "tune.txt"
+    monkeypatch.setenv("IAN_TUNE_CACHE", str(cache))
+    x = S.make_images(8, seed=3)
+    P = S.make_params("IAN_simple", 1)
+    m = IAN(os.path.join(CFG, "IAN_simple.py"), True, params=P)
+    try:
+        ref = m.reconstruct(x)
+        m.handle.autotune(8, 1)
+        first = cache.read_text().splitlines()
+        assert first[0].startswith("ian-tune-cache") and all(ln.split()[1] == "fwd" for ln in first[1:]) and len(first) > 5
+        assert np.array_equal(m.reconstruct(x), ref)                  # schedules change, bits do not
+        m.handle.set_option("tg_bf16x3", 1)
+        m.handle.set_option("tg_bf16x3_min_m", 1)
+        m.handle.autotune(8, 1)
+        both = cache.read_text().splitlines()
+        dirs = [ln.split()[1] for ln in both[1:]]
+        assert dirs.count("fwd") == len(first) - 1 and dirs.count("fwd+bf16x3") == len(first) - 1
+        assert [ln for ln in both[1:] if ln.split()[1] == "fwd"] == first[1:]      # the exact-fp32 choices were not touched
+        assert rel(m.reconstruct(x), ref) < TOL
+    finally:
+        m.close()
+
+
 def test_made_iaf_kernel_vs_reference_layers():
     """ian_k_made_iaf on the small-layer fixture: IAFLayer(z, MADE, MADE) as layers.py wires it."""
     import torch
