@@ -19,7 +19,7 @@ import dp_rehearsal  # noqa: E402  (tests/dp_rehearsal.py: the worker, shared wi
 # (world, global batch): the round-1..4 case, and BASELINE.json configs[4]'s WORLD SIZE at 16 images per rank (global 128): the 8-way
 # rank-ordered tree of the batch statistics, the MinibatchLayer over all 8 shards and the multi-bucket plans are driver-run (round 5 ran
 # 4 x 32 here).  The real shape, 8 x 128 = 1024, stays a committed record: scripts/exp/config5_rehearsal.py ->
-# profiles/r05_config5_rehearsal.json (~4 GPU-minutes, outside the suite's budget)
+# profiles/r06_config5_rehearsal.json (r05_ for the round-5 kernels; ~4 GPU-minutes, outside the suite's budget)
 @pytest.mark.parametrize("world,B", [(2, 4), (8, 128)])
 def test_sharded_step_equals_single_process_step(world, B, tmp_path, monkeypatch):
     # Split-K schedules are a function of the per-rank batch: with them on, the same image's activations differ in the last bit

@@ -173,7 +173,7 @@ def test_tune_cache_keeps_the_split_bf16_choices_apart(tmp_path, monkeypatch):
         m.handle.autotune(8, 1)
         first = cache.read_text().splitlines()
         assert first[0].startswith("ian-tune-cache") and all(ln.split()[1] == "fwd" for ln in first[1:]) and len(first) > 5
-        assert np.array_equal(m.reconstruct(x), ref)                  # schedules change, bits do not
+        assert rel(m.reconstruct(x), ref) < 1e-5                      # tuned split-K limits move the fp32 summation order, nothing else
         m.handle.set_option("tg_bf16x3", 1)
         m.handle.set_option("tg_bf16x3_min_m", 1)
         m.handle.autotune(8, 1)

@@ -169,7 +169,7 @@ def test_generator_update_at_a_quarter_of_the_benchmarked_batch():
     """update_gen's gradients (decoder_params, Z_params: train_IAN.py:256-273) on 32 images (round 6: 128 until then -- 148 s of the
     suite's 734, almost all of it the twin's float64 backward on the host; the kernels AT 128 images are held by the per-layer
     tests of this file, by the 8 x 16 sharded step that must equal the single-process 128-image step (tests/test_gpu_dp.py) and by
-    the committed 128-image decomposition record, profiles/r05_decomposition_b128_gen.json) vs float64 autograd of the
+    the committed 128-image decomposition record, profiles/r06_decomposition_b128_gen.json; r05_ for the round-5 kernels) vs float64 autograd of the
     twin; the encoder passes on X_hat / X_gen are fed the twin's images, as in test_gpu_train.test_gradients_match_autograd.
     Bars are multiples of what a float32 evaluation of the SAME restatement (torch-CPU twin, float32 vs float64, these
     inputs; 8 minutes of CPU, so measured once and recorded here) moves each group by -- round 3, with the reference's
